@@ -1,0 +1,214 @@
+/*
+ * sv_hip.h — C ABI of libsv_hip, the MI355X (gfx950) stereo disparity backend.
+ *
+ * This is the drop-in boundary for ONE path of robotology/stereo-vision:
+ *   StereoMatcherNew::compute() -> rectify -> SGM disparity16 -> LR / median /
+ *   speckle -> depth   (reference: modules/DisparityModule/StereoMatcher.cpp:57-79).
+ *
+ * The reference's own GPU back-end is bound through three plain functions
+ *   void    cuda_init(SGM_PARAMS*)                    sgbm_cuda/bova_sgm.cu:33-41
+ *   cv::Mat compute_disparity(cv::Mat*,cv::Mat*,float*) sgbm_cuda/bova_sgm.cu:43-328
+ *   cv::Mat zy_remap(cv::Mat&,cv::Mat&)               sgbm_cuda/main.cpp:106-109
+ * declared in sgbm_cuda_header.h and called from StereoMatcherNew::matchSGBMCUDA()
+ * (StereoMatcher.cpp:420-440) and updateCUDAParams() (StereoMatcher.cpp:271-289).
+ * libsv_hip replaces exactly those three entry points (plus the OpenCV calls
+ * that surround them on the path) with an opaque-context C ABI: plain pointers
+ * and sizes, no cv::Mat, no torch types, no global state, no exit().
+ *
+ * Conventions
+ *   - every call returns 0 on success, a negative sv_status on failure;
+ *     sv_last_error(ctx) returns a human-readable string (never NULL).
+ *   - pointer arguments named *_dev are DEVICE pointers (HBM) on the context's
+ *     GPU; *_host are host pointers.  Strides are in BYTES.
+ *   - a context is single-threaded (the reference serialises compute() under
+ *     mutexDisp, DispModule.cpp:713-717); different contexts may be used from
+ *     different threads / streams concurrently.
+ *   - all work of a context is enqueued on the context's HIP stream
+ *     (sv_set_stream); *_host entry points synchronise that stream before
+ *     returning, *_dev entry points do not.
+ */
+#ifndef SV_HIP_H
+#define SV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SV_ABI_VERSION 1
+
+/* disparity16 contract: StereoMatcher.h:105-106, sgbm_cuda/common.h:17-19 */
+#define SV_DISP_SCALE 16
+#define SV_DISP_SHIFT 4
+#define SV_INVALID_DISP_SCALED (-16)
+
+typedef enum sv_status {
+    SV_OK = 0,
+    SV_ERR_INVALID_ARG = -1,  /* NULL pointer, bad size, unsupported parameter  */
+    SV_ERR_UNSUPPORTED = -2,  /* parameter combination the kernels do not cover */
+    SV_ERR_NO_DEVICE = -3,    /* no HIP device / wrong architecture             */
+    SV_ERR_HIP = -4,          /* a HIP runtime call failed (see sv_last_error)  */
+    SV_ERR_NO_MAPS = -5,      /* rectify / depth requested before maps uploaded */
+    SV_ERR_NOMEM = -6
+} sv_status;
+
+/* Direction bits of the SGM paths (predecessor of pixel p is p - r).           */
+/* SURVEY Appendix A5; reference kernels aggregation.cu:60 (LR) :147 (UD_LR)    */
+/* :308 (UD) :388 (RL_UD) :546 (RL); the last three bits are the second sweep   */
+/* of OpenCV MODE_HH (StereoMatcher.cpp:409).                                   */
+#define SV_PATH_R 0x01  /* r=(+1, 0)  left  -> right                           */
+#define SV_PATH_DR 0x02 /* r=(+1,+1)  down-right                               */
+#define SV_PATH_D 0x04  /* r=( 0,+1)  top   -> bottom                          */
+#define SV_PATH_DL 0x08 /* r=(-1,+1)  down-left                                */
+#define SV_PATH_L 0x10  /* r=(-1, 0)  right -> left                            */
+#define SV_PATH_UL 0x20 /* r=(-1,-1)  up-left                                  */
+#define SV_PATH_U 0x40  /* r=( 0,-1)  bottom-> top                             */
+#define SV_PATH_UR 0x80 /* r=(+1,-1)  up-right                                 */
+#define SV_PATHS_5 0x1F /* the reference CUDA back-end (bova_sgm.cu:108-126)   */
+#define SV_PATHS_8 0xFF /* MODE_HH, what matchSGBM() asks for                  */
+
+/* Variant flags: each selects between the in-repo   */
+/* CUDA statement (REPO) and the restated OpenCV behaviour (EXT).               */
+#define SV_FLAG_C_COL0_P2 0x01      /* C[y>0][x=D] = P2 (MODE_HH) instead of a copy of row 0 (costs.cu:254-267) */
+#define SV_FLAG_C_TAIL_P2 0x02      /* C[y>H-1-SH2] = P2 (MODE_HH) instead of a copy of the previous row (costs.cu:279-282) */
+#define SV_FLAG_LR_OPENCV 0x04      /* LR threshold = disp12MaxDiff>0 ? disp12MaxDiff : 1 instead of the raw value (aggregation.cu:732) */
+#define SV_FLAG_MEDIAN_REPLICATE 0x08 /* cv::medianBlur border replication instead of unfiltered borders (aggregation.cu:765-767) */
+#define SV_FLAG_NO_LRCHECK 0x10     /* skip the left-right check (disp12MaxDiff < 0 in OpenCV) */
+#define SV_FLAG_NO_MEDIAN 0x20      /* skip the 3x3 median */
+#define SV_FLAGS_REPO 0x00          /* SGBM5_REPO: bit-faithful to the sgbm_cuda kernels */
+#define SV_FLAGS_HH (SV_FLAG_C_COL0_P2 | SV_FLAG_C_TAIL_P2 | SV_FLAG_LR_OPENCV | SV_FLAG_MEDIAN_REPLICATE)
+
+/*
+ * Parameter block.  Replaces SGM_PARAMS (sgbm_cuda/common.h:27-36) and the
+ * matcher part of Params (StereoMatcher.h:55-75).  Unlike the reference,
+ * num_disparities is honoured at run time (the CUDA code ignores it,
+ * common.h:16) and pre_filter_cap changes take effect (bova_sgm.cu:51-78
+ * builds the clip table only once).
+ */
+typedef struct sv_params {
+    int32_t min_disparity;       /* must be 0 (module default, DispModule.cpp:377)      */
+    int32_t num_disparities;     /* D: multiple of 32, 32..256 (DispModule.cpp:1355-1420) */
+    int32_t block_size;          /* SADWindowSize, odd, 1..11                            */
+    int32_t P1;                  /* 8*BS*BS  (StereoMatcher.cpp:279)                     */
+    int32_t P2;                  /* 32*BS*BS (StereoMatcher.cpp:280)                     */
+    int32_t pre_filter_cap;      /* 1..63                                                */
+    int32_t uniqueness_ratio;    /* 0..100                                               */
+    int32_t disp12_max_diff;     /* LR threshold, see SV_FLAG_LR_OPENCV                  */
+    int32_t speckle_window_size; /* 0 = off (reference CUDA path has none)               */
+    int32_t speckle_range;       /* maxDiff = 16*speckle_range                           */
+    uint32_t path_mask;          /* SV_PATHS_5 / SV_PATHS_8 / any non-empty subset       */
+    uint32_t flags;              /* SV_FLAG_*                                            */
+    float wls_lambda;            /* StereoMatcher.cpp:154                                */
+    float wls_sigma;             /* StereoMatcher.cpp:155                                */
+} sv_params;
+
+typedef struct sv_ctx sv_ctx;
+
+/* Fill *p with the module defaults (DispModule.cpp:369-394, numDisparities as
+ * given) for the gray/x1 cost variant of the CUDA back-end.  paths = 5 or 8. */
+int sv_default_params(sv_params* p, int num_disparities, int paths);
+
+/* Replaces the lazy first-call allocation of compute_disparity
+ * (bova_sgm.cu:51-78).  Allocates every device buffer for a width x height
+ * frame on HIP device `device`.  The context owns them until sv_destroy. */
+int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* params);
+
+/* Replaces free_gpu_mem (bova_sgm.cu:331-351, never called by the reference). */
+int sv_destroy(sv_ctx* ctx);
+
+/* Replaces cuda_init(SGM_PARAMS*) (bova_sgm.cu:33-41) as called from
+ * updateCUDAParams (StereoMatcher.cpp:271-289).  Reallocates if D changed.   */
+int sv_set_params(sv_ctx* ctx, const sv_params* params);
+int sv_get_params(const sv_ctx* ctx, sv_params* params);
+
+/* All later work of ctx is enqueued on `hip_stream` (a hipStream_t; NULL = the
+ * default stream).  No counterpart in the reference (it uses the default
+ * stream and cudaDeviceSynchronize after every kernel, bova_sgm.cu:92-130).  */
+int sv_set_stream(sv_ctx* ctx, void* hip_stream);
+
+/* Replaces zy_remap / compute_disparity (main.cpp:106-109, bova_sgm.cu:43-328):
+ * 8-bit gray rectified pair in host memory -> disparity16 in host memory.
+ * Columns [0, D) are written as SV_INVALID_DISP_SCALED (the reference leaves
+ * them uninitialised, bova_sgm.cu:67).                                        */
+int sv_compute_gray_host(sv_ctx* ctx, const uint8_t* left_host, size_t left_stride,
+                         const uint8_t* right_host, size_t right_stride,
+                         int16_t* disp16_host, size_t disp_stride);
+
+/* Same path with inputs and output already resident in HBM (dense rows:
+ * stride = width resp. 2*width bytes).  Asynchronous on the context stream.   */
+int sv_compute_gray_dev(sv_ctx* ctx, const uint8_t* left_dev, const uint8_t* right_dev,
+                        int16_t* disp16_dev);
+
+/* Replaces the two cv::cvtColor(.., CV_BGR2GRAY) calls of matchSGBMCUDA
+ * (StereoMatcher.cpp:429-430) applied to RGB-ordered bytes; 3 bytes/pixel in,
+ * 1 byte/pixel out, both on the device.                                       */
+int sv_gray_from_rgb_dev(sv_ctx* ctx, const uint8_t* rgb_dev, uint8_t* gray_dev);
+
+/* Replaces the map upload implicit in StereoCamera::rectifyImages
+ * (stereoCamera.cpp:569-574): four CV_32FC1 maps (map11,map12,map21,map22),
+ * width*height floats each, host memory.                                      */
+int sv_upload_maps_host(sv_ctx* ctx, const float* map_lx, const float* map_ly,
+                        const float* map_rx, const float* map_ry);
+
+/* Replaces one cv::remap(.., INTER_LINEAR) (BORDER_CONSTANT 0) of
+ * rectifyImages (stereoCamera.cpp:573-574) on an 8UC3 image.  which = 0 left,
+ * 1 right.  src/dst are device pointers, 3 bytes/pixel, dense.                */
+int sv_remap_rgb_dev(sv_ctx* ctx, int which, const uint8_t* src_rgb_dev, uint8_t* dst_rgb_dev);
+
+/* The whole of compute() for SGBM_HIP: remap both RGB images, convert to gray,
+ * match.  RGB host images in, disparity16 host out; the rectified RGB pair is
+ * kept on the device for the WLS guide and can be read back with
+ * sv_get_rectified_host.                                                      */
+int sv_compute_rgb_host(sv_ctx* ctx, const uint8_t* left_rgb_host, size_t left_stride,
+                        const uint8_t* right_rgb_host, size_t right_stride, int rectify,
+                        int16_t* disp16_host, size_t disp_stride);
+int sv_get_rectified_host(sv_ctx* ctx, int which, uint8_t* rgb_host, size_t stride);
+
+/* Replaces cv::ximgproc::getDisparityVis(disp16, vis, 3)
+ * (StereoMatcher.cpp:437): u8 = saturate(round_half_even(disp16*scale/16)).   */
+int sv_disparity_vis_dev(sv_ctx* ctx, const int16_t* disp16_dev, uint8_t* vis_dev, int scale);
+int sv_disparity_vis_host(sv_ctx* ctx, const int16_t* disp16_host, uint8_t* vis_host, int scale);
+
+/* Replaces cv::filterSpeckles inside cv::StereoSGBM::compute (called by
+ * matchSGBM, StereoMatcher.cpp:412) on a device disparity16 image, in place.  */
+int sv_filter_speckles_dev(sv_ctx* ctx, int16_t* disp16_dev, int max_size, int max_diff);
+
+/* Replaces DispModule::depthFromDisparity (DispModule.cpp:320-366), with the
+ * non-aliased read.  mapper = MapperL (CV_32FC2,
+ * width*height*2 floats), Q 4x4 and R 3x3 row-major doubles, host memory.     */
+int sv_depth_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride,
+                  const float* mapper_host, const double* Q, const double* R, float* depth_host,
+                  size_t depth_stride);
+int sv_depth_dev(sv_ctx* ctx, const int16_t* disp16_dev, const float* mapper_dev, const double* Q,
+                 const double* R, float* depth_dev);
+
+/* Stage access for parity tests and profiling (no counterpart in the
+ * reference beyond the #if 0 dump blocks, bova_sgm.cu:141-321).  Copies the
+ * internal [H][W-D][D] int16 volumes of the LAST sv_compute_* call to host.
+ * which: 0 = C (matching cost + P2), 1 = S (aggregated).                       */
+int sv_debug_read_volume_host(sv_ctx* ctx, int which, int16_t* vol_host, size_t n_elems);
+/* which: 0 = disp before LR check, 1 = raw integer disparity, 2 = minS,
+ * 3 = disp after LR check (before median).  width*height int16.               */
+int sv_debug_read_plane_host(sv_ctx* ctx, int which, int16_t* plane_host);
+
+/* Per-stage GPU time of the last sv_compute_* call in milliseconds, measured
+ * with HIP events on the context stream (enable with sv_enable_timing).
+ * Order: 0 prefilter, 1 cost, 2 aggregation, 3 wta, 4 lr+median(+speckle),
+ * 5 total.  Replaces the commented PROF_S/PROF_E macros (DispModule.cpp:24-69). */
+#define SV_N_TIMINGS 6
+int sv_enable_timing(sv_ctx* ctx, int enable);
+int sv_get_timings(sv_ctx* ctx, float* ms, int n);
+
+/* Algorithmic bytes per frame of the current geometry:
+ * which: 0 cost, 1 aggregation, 2 wta, 3 tail, 4 frame.                       */
+int64_t sv_algorithmic_bytes(const sv_ctx* ctx, int which);
+
+const char* sv_last_error(const sv_ctx* ctx);
+const char* sv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SV_HIP_H */

@@ -1,0 +1,528 @@
+/*
+ * sv_ref.c — CPU oracle for the stereo hot path.  TEST INFRASTRUCTURE ONLY; see
+ * sv_ref.h for the "parity unpinned" statement and for who may call this.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference/modules/DisparityModule/ unless stated).  "REPO" = read from
+ * the in-tree CUDA statement of the arithmetic; "EXT" = OpenCV behaviour the
+ * reference relies on but does not contain.
+ */
+#include "sv_ref.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SHRT_MAX_I 32767
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+const char* svref_version(void) { return "sv_ref 1 (restated SGBM, parity unpinned)"; }
+
+/* Limits under which every int16 store of the reference is wrap-free, so the
+ * restatement (and the GPU) may compute windows directly instead of through
+ * the reference's running sums.  Even block sizes are rejected (Appendix A9b:
+ * REPO and EXT disagree there). */
+int svref_check_params(const svref_params* p, int W, int H) {
+    if (!p) return -1;
+    int D = p->num_disparities, BS = p->block_size;
+    if (p->min_disparity != 0) return -2;
+    if (D < 32 || D > 256 || (D % 32) != 0) return -2;
+    if (BS < 1 || BS > 11 || (BS % 2) == 0) return -2;
+    if (W <= D || H < BS || W - D < BS) return -1;
+    if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63) return -2;
+    if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return -2;
+    /* max per-pixel BT cost: 2*cap (gradient channel) + 255>>2 (raw channel) */
+    long cmax = (long)(2 * p->pre_filter_cap + 63) * BS * BS + p->P2;
+    if (cmax > 32767) return -2;
+    if ((long)p->P1 + 32767 > 65535) return -2;
+    if (p->uniqueness_ratio < 0 || p->uniqueness_ratio > 100) return -2;
+    if ((p->path_mask & 0xFF) == 0 || (p->path_mask & ~0xFFu)) return -2;
+    return 0;
+}
+
+/* A1 REPO costs.cu:116-166 (get_gradient) with the clip table of
+ * costs.cu:286-292 (fill_tab; TAB_OFS bova_sgm.cu:31) folded into clip().
+ * grad is computed from the UNMODIFIED image (the __syncthreads at :151 orders
+ * the phases); afterwards column 0 and W-1 of grad and of the raw channel are
+ * forced to tab[0] = ftzero (:153-164). */
+void svref_prefilter(const uint8_t* img, int W, int H, int cap, uint8_t* grad, uint8_t* raw_mod) {
+    const int ftzero = cap;
+    for (int y = 0; y < H; y++) {
+        const uint8_t* r0 = img + (size_t)y * W;
+        const uint8_t* rm = img + (size_t)imax(y - 1, 0) * W;
+        const uint8_t* rp = img + (size_t)imin(y + 1, H - 1) * W;
+        uint8_t* g = grad + (size_t)y * W;
+        uint8_t* rw = raw_mod + (size_t)y * W;
+        for (int x = 1; x < W - 1; x++) {
+            int v = (r0[x + 1] - r0[x - 1]) * 2 + rm[x + 1] - rm[x - 1] + rp[x + 1] - rp[x - 1];
+            g[x] = (uint8_t)(imin(imax(v, -ftzero), ftzero) + ftzero);
+            rw[x] = r0[x];
+        }
+        g[0] = g[W - 1] = (uint8_t)ftzero;
+        rw[0] = rw[W - 1] = (uint8_t)ftzero;
+    }
+}
+
+/* A2 REPO costs.cu:170-201 (get_pixel_diff), one channel, accumulated into
+ * pix[y][xl][d] (int16 store at :199). */
+static void bt_channel(const uint8_t* L, const uint8_t* R, int W, int H, int D, int shift, int16_t* pix) {
+    const int W1 = W - D;
+    for (int y = 0; y < H; y++) {
+        const uint8_t* l = L + (size_t)y * W;
+        const uint8_t* r = R + (size_t)y * W;
+        for (int x = D; x < W; x++) {
+            int u = l[x];
+            int ul = x > 0 ? (u + l[x - 1]) / 2 : u;
+            int ur = x < W - 1 ? (u + l[x + 1]) / 2 : u;
+            int u0 = imin(imin(ul, ur), u), u1 = imax(imax(ul, ur), u);
+            int16_t* out = pix + ((size_t)y * W1 + (x - D)) * D;
+            for (int d = 0; d < D; d++) {
+                int v = r[x - d];
+                int vl = x >= d + 1 ? (r[x - d - 1] + v) / 2 : v;
+                int vr = x < W + d - 1 ? (r[x - d + 1] + v) / 2 : v;
+                int v0 = imin(imin(vl, vr), v), v1 = imax(imax(vl, vr), v);
+                int c0 = imax(imax(0, u - v1), v0 - u);
+                int c1 = imax(imax(0, v - u1), u0 - v);
+                out[d] = (int16_t)(out[d] + (imin(c0, c1) >> shift));
+            }
+        }
+    }
+}
+
+/* A2-A4.  REPO: bova_sgm.cu:94-103 (stage order), costs.cu:203-233 (get_hsum),
+ * costs.cu:235-284 (get_cost).  Volumes are [H][W1][D], d innermost, over the
+ * computable columns x in [D, W) only. */
+int svref_cost_volume(const uint8_t* left, const uint8_t* right, int W, int H, const svref_params* p,
+                      int16_t* C, svref_stages* st) {
+    const int D = p->num_disparities, W1 = W - D, BS = p->block_size, SW2 = BS / 2, SH2 = BS / 2;
+    const int P2 = p->P2;
+    const size_t npx = (size_t)W * H, nvol = (size_t)W1 * H * D;
+    uint8_t* gl = (uint8_t*)malloc(npx);
+    uint8_t* gr = (uint8_t*)malloc(npx);
+    uint8_t* rl = (uint8_t*)malloc(npx);
+    uint8_t* rr = (uint8_t*)malloc(npx);
+    int16_t* pix = (int16_t*)calloc(nvol, sizeof(int16_t)); /* cudaMemset, bova_sgm.cu:94 */
+    int16_t* hs = (int16_t*)malloc(nvol * sizeof(int16_t));
+    if (!gl || !gr || !rl || !rr || !pix || !hs) {
+        free(gl); free(gr); free(rl); free(rr); free(pix); free(hs);
+        return -6;
+    }
+    svref_prefilter(left, W, H, p->pre_filter_cap, gl, rl);
+    svref_prefilter(right, W, H, p->pre_filter_cap, gr, rr);
+    bt_channel(gl, gr, W, H, D, 0, pix); /* bova_sgm.cu:95 */
+    bt_channel(rl, rr, W, H, D, 2, pix); /* bova_sgm.cu:97 */
+
+    /* A3 horizontal box, costs.cu:214-232 */
+    for (int y = 0; y < H; y++) {
+        const int16_t* px = pix + (size_t)y * W1 * D;
+        int16_t* h = hs + (size_t)y * W1 * D;
+        for (int d = 0; d < D; d++) {
+            int acc = 0;
+            for (int k = 0; k <= SW2; k++) acc += px[(size_t)k * D + d] * (k == 0 ? SW2 + 1 : 1);
+            h[d] = (int16_t)acc;
+        }
+        for (int xl = 1; xl < W1; xl++) {
+            const int16_t* add = px + (size_t)imin(xl + SW2, W1 - 1) * D;
+            const int16_t* sub = px + (size_t)imax(xl - SW2 - 1, 0) * D;
+            const int16_t* prev = h + (size_t)(xl - 1) * D;
+            int16_t* cur = h + (size_t)xl * D;
+            for (int d = 0; d < D; d++) cur[d] = (int16_t)(prev[d] + add[d] - sub[d]);
+        }
+    }
+
+    /* A4 vertical box + P2, costs.cu:244-283 */
+    const size_t rowN = (size_t)W1 * D;
+    for (int xl = 0; xl < W1; xl++) {
+        for (int d = 0; d < D; d++) {
+            size_t o = (size_t)xl * D + d;
+            int acc = P2;
+            for (int i = 0; i <= SH2; i++) acc += hs[(size_t)i * rowN + o] * (i == 0 ? SH2 + 1 : 1);
+            C[o] = (int16_t)acc;
+        }
+    }
+    for (int y = 1; y < H; y++) {
+        const int k = y + SH2;
+        int16_t* c = C + (size_t)y * rowN;
+        const int16_t* cp = C + (size_t)(y - 1) * rowN;
+        if (k < H) {
+            const int16_t* add = hs + (size_t)k * rowN;
+            const int16_t* sub = hs + (size_t)(k >= BS ? k - BS : 0) * rowN;
+            /* xl = 0: "copy opencv" quirk, costs.cu:254-267 */
+            for (int d = 0; d < D; d++) c[d] = cp[d];
+            for (size_t o = D; o < rowN; o++) c[o] = (int16_t)(cp[o] + add[o] - sub[o]);
+        } else {
+            /* bottom SH2 rows keep the previous row, costs.cu:263-266,279-282 */
+            memcpy(c, cp, rowN * sizeof(int16_t));
+        }
+    }
+    /* EXT MODE_HH alternatives (Appendix A4): rows own their C buffer there, so
+     * what REPO leaves as a copy is the initial P2. */
+    if (p->flags & SVREF_FLAG_C_TAIL_P2)
+        for (int y = imax(H - SH2, 1); y < H; y++) {
+            int16_t* c = C + (size_t)y * rowN;
+            for (size_t o = 0; o < rowN; o++) c[o] = (int16_t)P2;
+        }
+    if (p->flags & SVREF_FLAG_C_COL0_P2)
+        for (int y = 1; y < H; y++) {
+            int16_t* c = C + (size_t)y * rowN;
+            for (int d = 0; d < D; d++) c[d] = (int16_t)P2;
+        }
+
+    if (st) {
+        if (st->grad_l) memcpy(st->grad_l, gl, npx);
+        if (st->grad_r) memcpy(st->grad_r, gr, npx);
+        if (st->raw_l) memcpy(st->raw_l, rl, npx);
+        if (st->raw_r) memcpy(st->raw_r, rr, npx);
+        if (st->pix) memcpy(st->pix, pix, nvol * sizeof(int16_t));
+        if (st->hsum) memcpy(st->hsum, hs, nvol * sizeof(int16_t));
+        if (st->C) memcpy(st->C, C, nvol * sizeof(int16_t));
+    }
+    free(gl); free(gr); free(rl); free(rr); free(pix); free(hs);
+    return 0;
+}
+
+static const int DIR_DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+static const int DIR_DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+
+/* A5.  REPO aggregation.cu:60-141 (LR), :147-306 (UD_LR), :308-385 (UD),
+ * :388-543 (RL_UD), :546-625 (RL); the three upward directions are the second
+ * sweep of EXT MODE_HH with the identical recurrence.  A predecessor outside
+ * [0,W1)x[0,H) is a fresh path start (Lp == 0, delta = P2): that is what the
+ * kernels do at row 0 (:75-86) and what the diagonal kernels do when they wrap
+ * at an image edge (:233-256, :469-492).  Unlike REPO (Appendix A5 caveat) every
+ * pixel is covered whatever the aspect ratio.  safe_add: aggregation.cu:4-10. */
+void svref_aggregate_path(const int16_t* C, int W1, int H, int D, int P1, int P2, int dir, int16_t* S,
+                          int16_t* L_out) {
+    const int dx = DIR_DX[dir], dy = DIR_DY[dir];
+    const size_t rowN = (size_t)W1 * D;
+    /* L rows carry guard entries at d = -1 and d = D (lr_pre[-1], lr_pre[D] = SHRT_MAX, :78) */
+    const int DP = D + 2;
+    int16_t* rows = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)W1 * DP);
+    int* mins = (int*)malloc(sizeof(int) * 2 * (size_t)W1);
+    int16_t* fresh = (int16_t*)calloc(DP, sizeof(int16_t));
+    fresh[0] = fresh[D + 1] = SHRT_MAX_I;
+    for (size_t i = 0; i < 2 * (size_t)W1; i++) rows[i * DP] = rows[i * DP + D + 1] = SHRT_MAX_I;
+
+    for (int iy = 0; iy < H; iy++) {
+        const int y = dy < 0 ? H - 1 - iy : iy;
+        int16_t* cur = rows + (size_t)(iy & 1) * W1 * DP;
+        int16_t* prv = rows + (size_t)((iy & 1) ^ 1) * W1 * DP;
+        int* curmin = mins + (size_t)(iy & 1) * W1;
+        int* prvmin = mins + (size_t)((iy & 1) ^ 1) * W1;
+        const int py = y - dy;
+        for (int ix = 0; ix < W1; ix++) {
+            const int x = dx < 0 ? W1 - 1 - ix : ix;
+            const int px = x - dx;
+            const int has_pred = px >= 0 && px < W1 && py >= 0 && py < H;
+            const int16_t* Lp = fresh + 1;
+            int delta = P2;
+            if (has_pred) {
+                if (dy == 0) {
+                    Lp = cur + (size_t)px * DP + 1;
+                    delta = curmin[px] + P2;
+                } else {
+                    Lp = prv + (size_t)px * DP + 1;
+                    delta = prvmin[px] + P2;
+                }
+            }
+            const int16_t* c = C + (size_t)y * rowN + (size_t)x * D;
+            int16_t* s = S + (size_t)y * rowN + (size_t)x * D;
+            int16_t* Lc = cur + (size_t)x * DP + 1;
+            int mn = SHRT_MAX_I;
+            for (int d = 0; d < D; d++) {
+                int m = imin(imin((int)Lp[d], Lp[d - 1] + P1), imin(Lp[d + 1] + P1, delta));
+                int l = c[d] + m - delta;
+                Lc[d] = (int16_t)l;
+                mn = imin(mn, l);
+                int t = s[d] + l;
+                s[d] = (int16_t)(t > SHRT_MAX_I ? SHRT_MAX_I : t);
+            }
+            curmin[x] = mn;
+            if (L_out) memcpy(L_out + (size_t)y * rowN + (size_t)x * D, Lc, sizeof(int16_t) * D);
+        }
+    }
+    free(rows);
+    free(mins);
+    free(fresh);
+}
+
+/* A6.  REPO aggregation.cu:629-689 (get_disparity).  Full-width planes; columns
+ * [0,D) get the contract value (Appendix A9).  raw = -1 marks "no disparity"
+ * (REPO writes INVALID_DISP_SCALED there, :642; same meaning). */
+void svref_wta(const int16_t* S, int W, int H, int D, int uniq, int16_t* disp, int16_t* raw, int16_t* mins) {
+    const int W1 = W - D;
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            size_t o = (size_t)y * W + x;
+            disp[o] = SVREF_INVALID;
+            raw[o] = -1;
+            mins[o] = SHRT_MAX_I;
+            if (x < D) continue;
+            const int16_t* s = S + ((size_t)y * W1 + (x - D)) * D;
+            int minS = SHRT_MAX_I, best = -1;
+            for (int d = 0; d < D; d++)
+                if (minS > s[d]) { minS = s[d]; best = d; }
+            mins[o] = (int16_t)minS;
+            if (best < 0) continue; /* every S saturated: no minimum, invalid */
+            int d;
+            for (d = 0; d < D; d++)
+                if (s[d] * (100 - uniq) < minS * 100 && abs(best - d) > 1) break;
+            if (d < D) continue;
+            raw[o] = (int16_t)best;
+            int v;
+            if (0 < best && best < D - 1) {
+                int denom2 = imax(s[best - 1] + s[best + 1] - 2 * s[best], 1);
+                v = best * 16 + ((s[best - 1] - s[best + 1]) * 16 + denom2) / (denom2 * 2);
+            } else
+                v = best * 16;
+            disp[o] = (int16_t)v;
+        }
+    }
+}
+
+/* A7.  REPO aggregation.cu:691-735 (lrcheck).  disp2 is built right to left
+ * with a strict '>' so ties keep the larger x (:706-719). */
+void svref_lrcheck(int16_t* disp, const int16_t* raw, const int16_t* mins, int W, int H, int D, int thresh,
+                   int16_t* disp2_out) {
+    int16_t* disp2 = (int16_t*)malloc(sizeof(int16_t) * W);
+    int16_t* d2c = (int16_t*)malloc(sizeof(int16_t) * W);
+    for (int y = 0; y < H; y++) {
+        int16_t* dp = disp + (size_t)y * W;
+        const int16_t* rw = raw + (size_t)y * W;
+        const int16_t* mn = mins + (size_t)y * W;
+        for (int x = 0; x < W; x++) { d2c[x] = SHRT_MAX_I; disp2[x] = SVREF_INVALID; }
+        for (int x = W - 1; x >= D; x--) {
+            int d = rw[x];
+            if (d < 0) continue;
+            int x2 = x - d;
+            if (d2c[x2] > mn[x]) { d2c[x2] = mn[x]; disp2[x2] = (int16_t)d; }
+        }
+        for (int x = D; x < W; x++) {
+            int d1 = dp[x];
+            if (d1 == SVREF_INVALID) continue;
+            int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+            int _x = x - _d, x_ = x - d_;
+            if (0 <= _x && _x < W && disp2[_x] >= 0 && abs(disp2[_x] - _d) > thresh && 0 <= x_ && x_ < W &&
+                disp2[x_] >= 0 && abs(disp2[x_] - d_) > thresh)
+                dp[x] = SVREF_INVALID;
+        }
+        if (disp2_out) memcpy(disp2_out + (size_t)y * W, disp2, sizeof(int16_t) * W);
+    }
+    free(disp2);
+    free(d2c);
+}
+
+static int16_t median9(int16_t* w) {
+    /* partial selection sort, as aggregation.cu:753-764 */
+    for (int i = 0; i < 5; i++) {
+        int m = i;
+        for (int j = i + 1; j < 9; j++)
+            if (w[j] < w[m]) m = j;
+        int16_t t = w[i]; w[i] = w[m]; w[m] = t;
+    }
+    return w[4];
+}
+
+/* A8.  REPO aggregation.cu:737-768 (MedianFilter): interior 3x3 median, border
+ * pixels copied.  replicate = 1: EXT cv::medianBlur(.,3) border replication. */
+void svref_median3(const int16_t* in, int16_t* out, int W, int H, int replicate) {
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int border = (y < 1 || x < 1 || y >= H - 1 || x >= W - 1);
+            if (border && !replicate) { out[(size_t)y * W + x] = in[(size_t)y * W + x]; continue; }
+            int16_t w[9];
+            int n = 0;
+            for (int i = -1; i <= 1; i++)
+                for (int j = -1; j <= 1; j++) {
+                    int yy = imin(imax(y + i, 0), H - 1), xx = imin(imax(x + j, 0), W - 1);
+                    w[n++] = in[(size_t)yy * W + xx];
+                }
+            out[(size_t)y * W + x] = median9(w);
+        }
+}
+
+/* A10.  EXT cv::filterSpeckles (called inside cv::StereoSGBM::compute, which
+ * matchSGBM uses, StereoMatcher.cpp:412): 4-connected components over pixels
+ * != new_val, neighbours joined iff |delta| <= max_diff; components of size
+ * <= max_size are set to new_val.  Order-independent. */
+void svref_filter_speckles(int16_t* img, int W, int H, int new_val, int max_size, int max_diff) {
+    const size_t n = (size_t)W * H;
+    int32_t* label = (int32_t*)calloc(n, sizeof(int32_t));
+    int32_t* stack = (int32_t*)malloc(n * sizeof(int32_t));
+    uint8_t* small = (uint8_t*)malloc(n + 1);
+    int cur = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (img[i] == new_val) continue;
+        if (label[i]) {
+            if (small[label[i]]) img[i] = (int16_t)new_val;
+            continue;
+        }
+        int sp = 0, count = 0;
+        cur++;
+        label[i] = cur;
+        stack[sp++] = (int32_t)i;
+        while (sp) {
+            int32_t p = stack[--sp];
+            count++;
+            int py = p / W, px = p % W, v = img[p];
+            const int nb[4][2] = {{py, px + 1}, {py, px - 1}, {py + 1, px}, {py - 1, px}};
+            for (int k = 0; k < 4; k++) {
+                int yy = nb[k][0], xx = nb[k][1];
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                int32_t q = yy * W + xx;
+                if (label[q] || img[q] == new_val || abs(img[q] - v) > max_diff) continue;
+                label[q] = cur;
+                stack[sp++] = q;
+            }
+        }
+        small[cur] = count <= max_size;
+        if (small[cur]) img[i] = (int16_t)new_val;
+    }
+    free(label);
+    free(stack);
+    free(small);
+}
+
+/* Whole matcher.  Stage order: bova_sgm.cu:87-136; columns [0,D) = -16 (A9);
+ * median then speckle as cv::StereoSGBM::compute does (EXT). */
+int svref_sgbm(const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int W, int H,
+               const svref_params* p, int16_t* disp16, size_t ds, svref_stages* st) {
+    int rc = svref_check_params(p, W, H);
+    if (rc) return rc;
+    if (!left || !right || !disp16 || ls < (size_t)W || rs < (size_t)W || ds < (size_t)W * 2) return -1;
+    const int D = p->num_disparities, W1 = W - D;
+    const size_t npx = (size_t)W * H, nvol = (size_t)W1 * H * D;
+    uint8_t* l = (uint8_t*)malloc(npx);
+    uint8_t* r = (uint8_t*)malloc(npx);
+    int16_t* C = (int16_t*)malloc(nvol * sizeof(int16_t));
+    int16_t* S = (int16_t*)calloc(nvol, sizeof(int16_t)); /* cudaMemset, bova_sgm.cu:106 */
+    int16_t* disp = (int16_t*)malloc(npx * 2);
+    int16_t* raw = (int16_t*)malloc(npx * 2);
+    int16_t* mins = (int16_t*)malloc(npx * 2);
+    int16_t* med = (int16_t*)malloc(npx * 2);
+    if (!l || !r || !C || !S || !disp || !raw || !mins || !med) {
+        free(l); free(r); free(C); free(S); free(disp); free(raw); free(mins); free(med);
+        return -6;
+    }
+    for (int y = 0; y < H; y++) {
+        memcpy(l + (size_t)y * W, left + y * ls, W);
+        memcpy(r + (size_t)y * W, right + y * rs, W);
+    }
+    rc = svref_cost_volume(l, r, W, H, p, C, st);
+    if (rc == 0) {
+        for (int dir = 0; dir < 8; dir++)
+            if (p->path_mask & (1u << dir))
+                svref_aggregate_path(C, W1, H, D, p->P1, p->P2, dir, S, st ? st->L[dir] : NULL);
+        if (st && st->S) memcpy(st->S, S, nvol * sizeof(int16_t));
+        svref_wta(S, W, H, D, p->uniqueness_ratio, disp, raw, mins);
+        if (st && st->disp_wta) memcpy(st->disp_wta, disp, npx * 2);
+        if (st && st->raw) memcpy(st->raw, raw, npx * 2);
+        if (st && st->mins) memcpy(st->mins, mins, npx * 2);
+        if (!(p->flags & SVREF_FLAG_NO_LRCHECK)) {
+            int thr = p->disp12_max_diff;
+            if (p->flags & SVREF_FLAG_LR_OPENCV) thr = thr > 0 ? thr : 1; /* EXT, Appendix A7 */
+            svref_lrcheck(disp, raw, mins, W, H, D, thr, st ? st->disp2 : NULL);
+        }
+        if (st && st->disp_lr) memcpy(st->disp_lr, disp, npx * 2);
+        if (!(p->flags & SVREF_FLAG_NO_MEDIAN))
+            svref_median3(disp, med, W, H, (p->flags & SVREF_FLAG_MEDIAN_REPLICATE) != 0);
+        else
+            memcpy(med, disp, npx * 2);
+        if (st && st->disp_med) memcpy(st->disp_med, med, npx * 2);
+        if (p->speckle_window_size > 0)
+            svref_filter_speckles(med, W, H, SVREF_INVALID, p->speckle_window_size, 16 * p->speckle_range);
+        for (int y = 0; y < H; y++) memcpy((char*)disp16 + y * ds, med + (size_t)y * W, (size_t)W * 2);
+    }
+    free(l); free(r); free(C); free(S); free(disp); free(raw); free(mins); free(med);
+    return rc;
+}
+
+/* A11.  EXT cv::ximgproc::getDisparityVis(src, dst, scale) as called at
+ * StereoMatcher.cpp:437: dst = saturate_cast<uchar>(src * scale/16), rounded
+ * half to even (cvRound). */
+void svref_disparity_vis(const int16_t* disp16, uint8_t* vis, size_t n, int scale) {
+    for (size_t i = 0; i < n; i++) {
+        int v = disp16[i] * scale;
+        int q = v >> 4, r = v & 15; /* floor division */
+        if (r > 8 || (r == 8 && (q & 1))) q++;
+        vis[i] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+    }
+}
+
+/* A12.  EXT cv::cvtColor(CV_BGR2GRAY) applied to RGB-ordered bytes
+ * (StereoMatcher.cpp:429-430): byte 0 gets the "B" weight. */
+void svref_gray_from_rgb(const uint8_t* rgb, uint8_t* gray, size_t n) {
+    for (size_t i = 0; i < n; i++)
+        gray[i] = (uint8_t)((rgb[3 * i] * 1868 + rgb[3 * i + 1] * 9617 + rgb[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+}
+
+/* A13.  EXT cv::remap(src, dst, mapx, mapy, INTER_LINEAR) with CV_32FC1 maps and
+ * BORDER_CONSTANT(0) as called at stereoCamera.cpp:573-574: coordinates
+ * quantised to 1/32 px (round half even), 15-bit bilinear weights, out-of-image
+ * taps read 0. */
+void svref_remap_rgb(const uint8_t* src, int W, int H, const float* mapx, const float* mapy, uint8_t* dst) {
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            size_t o = (size_t)y * W + x;
+            float fxm = mapx[o] * 32.0f, fym = mapy[o] * 32.0f;
+            /* saturate like cvRound + saturate_cast<short>(>>5) */
+            if (!(fxm > -1.0e9f)) fxm = -1.0e9f;
+            if (!(fxm < 1.0e9f)) fxm = 1.0e9f;
+            if (!(fym > -1.0e9f)) fym = -1.0e9f;
+            if (!(fym < 1.0e9f)) fym = 1.0e9f;
+            long sx = lrintf(fxm), sy = lrintf(fym);
+            long ix = sx >> 5, iy = sy >> 5;
+            if (ix < -32768) ix = -32768;
+            if (ix > 32767) ix = 32767;
+            if (iy < -32768) iy = -32768;
+            if (iy > 32767) iy = 32767;
+            int fx = (int)(sx & 31), fy = (int)(sy & 31);
+            int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
+            int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+            for (int c = 0; c < 3; c++) {
+                int p00 = 0, p01 = 0, p10 = 0, p11 = 0;
+                int x0ok = ix >= 0 && ix < W, x1ok = ix + 1 >= 0 && ix + 1 < W;
+                int y0ok = iy >= 0 && iy < H, y1ok = iy + 1 >= 0 && iy + 1 < H;
+                if (y0ok && x0ok) p00 = src[((size_t)iy * W + ix) * 3 + c];
+                if (y0ok && x1ok) p01 = src[((size_t)iy * W + ix + 1) * 3 + c];
+                if (y1ok && x0ok) p10 = src[((size_t)(iy + 1) * W + ix) * 3 + c];
+                if (y1ok && x1ok) p11 = src[((size_t)(iy + 1) * W + ix + 1) * 3 + c];
+                int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+                dst[o * 3 + c] = (uint8_t)(v > 255 ? 255 : v);
+            }
+        }
+}
+
+/* A14.  REPO DispModule.cpp:320-366 (depthFromDisparity).  usign is compared
+ * with cols, vsign with rows (:358); coefficients are cast to float first
+ * (:333-343).  alias = 1: read the image being overwritten (:361), raster order. */
+void svref_depth(const int16_t* disp16, int W, int H, const float* mapper, const double* Q, const double* R,
+                 int alias, float* depth) {
+    const size_t n = (size_t)W * H;
+    float* src = depth;
+    for (size_t i = 0; i < n; i++) depth[i] = (float)disp16[i] * (float)(1. / 16.);
+    if (!alias) {
+        src = (float*)malloc(n * sizeof(float));
+        memcpy(src, depth, n * sizeof(float));
+    }
+    const float r02 = (float)R[2], r12 = (float)R[5], r22 = (float)R[8];
+    const float q00 = (float)Q[0], q03 = (float)Q[3], q11 = (float)Q[5], q13 = (float)Q[7];
+    const float q23 = (float)Q[11], q32 = (float)Q[14], q33 = (float)Q[15];
+    for (int u = 0; u < H; u++)
+        for (int v = 0; v < W; v++) {
+            size_t o = (size_t)u * W + v;
+            float usign = (float)lrintf(mapper[2 * o]);
+            float vsign = (float)lrintf(mapper[2 * o + 1]);
+            if (usign < 0 || usign >= W || vsign < 0 || vsign >= H)
+                depth[o] = 0.0f;
+            else {
+                float num = r02 * (vsign * q00 + q03) + r12 * (usign * q11 + q13) + r22 * q23;
+                float den = src[(size_t)vsign * W + (size_t)usign] * q32 + q33;
+                depth[o] = num / den;
+            }
+        }
+    if (!alias) free(src);
+}

@@ -1,0 +1,210 @@
+"""svref.py — ctypes access to oracle/libsv_ref.so (the CPU oracle).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package.  Parity unpinned
+(see oracle/sv_ref.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libsv_ref.so")
+
+INVALID = -16
+PATHS_5, PATHS_8 = 0x1F, 0xFF
+FLAG_C_COL0_P2, FLAG_C_TAIL_P2, FLAG_LR_OPENCV, FLAG_MEDIAN_REPLICATE = 1, 2, 4, 8
+FLAG_NO_LRCHECK, FLAG_NO_MEDIAN = 0x10, 0x20
+FLAGS_REPO = 0
+FLAGS_HH = FLAG_C_COL0_P2 | FLAG_C_TAIL_P2 | FLAG_LR_OPENCV | FLAG_MEDIAN_REPLICATE
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "min_disparity", "num_disparities", "block_size", "P1", "P2", "pre_filter_cap",
+        "uniqueness_ratio", "disp12_max_diff", "speckle_window_size", "speckle_range")] + [
+        ("path_mask", C.c_uint32), ("flags", C.c_uint32), ("wls_lambda", C.c_float), ("wls_sigma", C.c_float)]
+
+
+class Stages(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("grad_l", "grad_r", "raw_l", "raw_r", "pix", "hsum", "C")] + [
+        ("L", C.c_void_p * 8)] + [(n, C.c_void_p) for n in (
+            "S", "disp_wta", "raw", "mins", "disp2", "disp_lr", "disp_med")]
+
+
+def default_params(D, paths=8, BS=7, uniq=15, disp12=0, cap=63, speckle_window=0, speckle_range=0, flags=None,
+                   path_mask=None):
+    p = Params()
+    p.min_disparity, p.num_disparities, p.block_size = 0, D, BS
+    p.P1, p.P2, p.pre_filter_cap = 8 * BS * BS, 32 * BS * BS, cap
+    p.uniqueness_ratio, p.disp12_max_diff = uniq, disp12
+    p.speckle_window_size, p.speckle_range = speckle_window, speckle_range
+    p.path_mask = path_mask if path_mask is not None else (PATHS_8 if paths == 8 else PATHS_5)
+    p.flags = flags if flags is not None else (FLAGS_HH if paths == 8 else FLAGS_REPO)
+    p.wls_lambda, p.wls_sigma = 4500.0, 1.0
+    return p
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "sv_ref.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        if not os.path.exists(src):
+            raise RuntimeError("oracle source missing")
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libsv_ref.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.svref_version.restype = C.c_char_p
+        L.svref_sgbm.restype = C.c_int
+        L.svref_sgbm.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                 C.POINTER(Params), C.c_void_p, C.c_size_t, C.POINTER(Stages)]
+        L.svref_check_params.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
+        L.svref_cost_volume.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_void_p,
+                                        C.POINTER(Stages)]
+        L.svref_aggregate_path.restype = None
+        L.svref_aggregate_path.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
+        L.svref_wta.restype = None
+        L.svref_wta.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3
+        L.svref_median3.restype = None
+        L.svref_median3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.svref_filter_speckles.restype = None
+        L.svref_filter_speckles.argtypes = [C.c_void_p] + [C.c_int] * 5
+        L.svref_disparity_vis.restype = None
+        L.svref_disparity_vis.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.svref_gray_from_rgb.restype = None
+        L.svref_gray_from_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.svref_remap_rgb.restype = None
+        L.svref_remap_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.svref_depth.restype = None
+        L.svref_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_STAGE_SPECS = {
+    "grad_l": ("px", np.uint8), "grad_r": ("px", np.uint8), "raw_l": ("px", np.uint8), "raw_r": ("px", np.uint8),
+    "pix": ("vol", np.int16), "hsum": ("vol", np.int16), "C": ("vol", np.int16), "S": ("vol", np.int16),
+    "disp_wta": ("px", np.int16), "raw": ("px", np.int16), "mins": ("px", np.int16), "disp2": ("px", np.int16),
+    "disp_lr": ("px", np.int16), "disp_med": ("px", np.int16)}
+
+
+def sgbm(left, right, params, stages=(), path_L=False):
+    """Run the oracle.  Returns disp16 [H][W] int16 (and a dict of requested stages)."""
+    left = np.ascontiguousarray(left, np.uint8)
+    right = np.ascontiguousarray(right, np.uint8)
+    H, W = left.shape
+    D = params.num_disparities
+    out = np.empty((H, W), np.int16)
+    st = Stages()
+    keep = {}
+    for name in stages:
+        kind, dt = _STAGE_SPECS[name]
+        arr = np.zeros((H, W) if kind == "px" else (H, W - D, D), dt)
+        keep[name] = arr
+        setattr(st, name, _ptr(arr).value)
+    if path_L:
+        Ls = {}
+        for k in range(8):
+            if params.path_mask & (1 << k):
+                Ls[k] = np.zeros((H, W - D, D), np.int16)
+                st.L[k] = _ptr(Ls[k]).value
+        keep["L"] = Ls
+    rc = lib().svref_sgbm(_ptr(left), W, _ptr(right), W, W, H, C.byref(params), _ptr(out), 2 * W,
+                          C.byref(st) if (stages or path_L) else None)
+    if rc != 0:
+        raise ValueError("svref_sgbm failed: %d" % rc)
+    return (out, keep) if (stages or path_L) else out
+
+
+def cost_volume(left, right, params):
+    left = np.ascontiguousarray(left, np.uint8)
+    right = np.ascontiguousarray(right, np.uint8)
+    H, W = left.shape
+    D = params.num_disparities
+    Cv = np.empty((H, W - D, D), np.int16)
+    rc = lib().svref_cost_volume(_ptr(left), _ptr(right), W, H, C.byref(params), _ptr(Cv), None)
+    if rc:
+        raise ValueError("svref_cost_volume failed: %d" % rc)
+    return Cv
+
+
+def aggregate_path(Cv, P1, P2, direction, S=None):
+    H, W1, D = Cv.shape
+    Cv = np.ascontiguousarray(Cv, np.int16)
+    if S is None:
+        S = np.zeros_like(Cv)
+    L = np.empty_like(Cv)
+    lib().svref_aggregate_path(_ptr(Cv), W1, H, D, P1, P2, direction, _ptr(S), _ptr(L))
+    return S, L
+
+
+def wta(S, W, uniq):
+    H, W1, D = S.shape
+    S = np.ascontiguousarray(S, np.int16)
+    disp, raw, mins = (np.empty((H, W), np.int16) for _ in range(3))
+    lib().svref_wta(_ptr(S), W, H, D, uniq, _ptr(disp), _ptr(raw), _ptr(mins))
+    return disp, raw, mins
+
+
+def median3(img, replicate=False):
+    img = np.ascontiguousarray(img, np.int16)
+    out = np.empty_like(img)
+    lib().svref_median3(_ptr(img), _ptr(out), img.shape[1], img.shape[0], int(replicate))
+    return out
+
+
+def filter_speckles(img, new_val, max_size, max_diff):
+    out = np.ascontiguousarray(img, np.int16).copy()
+    lib().svref_filter_speckles(_ptr(out), out.shape[1], out.shape[0], new_val, max_size, max_diff)
+    return out
+
+
+def disparity_vis(disp16, scale=3):
+    d = np.ascontiguousarray(disp16, np.int16)
+    out = np.empty(d.shape, np.uint8)
+    lib().svref_disparity_vis(_ptr(d), _ptr(out), d.size, scale)
+    return out
+
+
+def gray_from_rgb(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    out = np.empty(rgb.shape[:2], np.uint8)
+    lib().svref_gray_from_rgb(_ptr(rgb), _ptr(out), out.size)
+    return out
+
+
+def remap_rgb(src, mapx, mapy):
+    src = np.ascontiguousarray(src, np.uint8)
+    mapx = np.ascontiguousarray(mapx, np.float32)
+    mapy = np.ascontiguousarray(mapy, np.float32)
+    H, W = src.shape[:2]
+    out = np.empty_like(src)
+    lib().svref_remap_rgb(_ptr(src), W, H, _ptr(mapx), _ptr(mapy), _ptr(out))
+    return out
+
+
+def depth(disp16, mapper, Q, R, alias=False):
+    d = np.ascontiguousarray(disp16, np.int16)
+    H, W = d.shape
+    mapper = np.ascontiguousarray(mapper, np.float32)
+    Q = np.ascontiguousarray(Q, np.float64)
+    R = np.ascontiguousarray(R, np.float64)
+    out = np.empty((H, W), np.float32)
+    lib().svref_depth(_ptr(d), W, H, _ptr(mapper), _ptr(Q), _ptr(R), int(alias), _ptr(out))
+    return out

@@ -1,0 +1,606 @@
+// sv_hip.hip — C ABI of libsv_hip (include/sv_hip.h): context, buffers, launch order.
+//
+// Launch order per frame = the stage order of compute_disparity
+// (/root/reference/modules/DisparityModule/sgbm_cuda/bova_sgm.cu:87-136) without its
+// cudaDeviceSynchronize() after every kernel, its two volume memsets and its blocking copies:
+// everything is enqueued on one HIP stream; the host variant synchronises once at the end.
+#include "../../include/sv_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "sv_kernels.hip.h"
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t n = 0;
+};
+
+}  // namespace
+
+struct sv_ctx {
+    int device = 0;
+    int W = 0, H = 0;
+    sv_params prm{};
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+
+    // device buffers
+    Buf img_l, img_r;        // u8 [H][W] staging for the host entry points
+    Buf stat_l, stat_r;      // uint2 [H][W]
+    Buf hs, C, S;            // u16 [H][W1][D]
+    Buf disp, raw, mins;     // i16 [H][W]
+    Buf disp_lr, out;        // i16 [H][W]
+    Buf rgb_l, rgb_r;        // u8 [H][W][3] input staging
+    Buf rect_l, rect_r;      // u8 [H][W][3] rectified
+    Buf gray_l, gray_r;      // u8 [H][W]
+    Buf maps[4];             // f32 [H][W]
+    Buf mapper;              // f32 [H][W][2]
+    Buf depth;               // f32 [H][W]
+    Buf d16tmp;              // i16 [H][W] staging for host helper entry points
+    Buf vis;                 // u8 [H][W]
+    Buf lab, cnt;            // int [H][W] speckle union-find
+    bool have_maps = false;
+
+    bool timing = false;
+    hipEvent_t ev[SV_N_TIMINGS + 1] = {};
+    bool ev_ok = false;
+    float ms[SV_N_TIMINGS] = {0};
+    bool ms_valid = false;
+};
+
+namespace {
+
+const char* k_noctx = "null context";
+
+int fail(sv_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail((c), SV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int check_params(sv_ctx* c, const sv_params* p, int W, int H) {
+    if (!p) return fail(c, SV_ERR_INVALID_ARG, "params is NULL");
+    const int D = p->num_disparities, BS = p->block_size;
+    if (p->min_disparity != 0) return fail(c, SV_ERR_UNSUPPORTED, "min_disparity must be 0 (got %d)", p->min_disparity);
+    if (D < 32 || D > 256 || (D % 32) != 0)
+        return fail(c, SV_ERR_UNSUPPORTED, "num_disparities must be a multiple of 32 in [32,256] (got %d)", D);
+    if (BS < 1 || BS > 11 || (BS % 2) == 0)
+        return fail(c, SV_ERR_UNSUPPORTED, "block_size must be odd in [1,11] (got %d)", BS);
+    if (W <= D || H < BS || W - D < BS || W > 65535 || H > 65535)
+        return fail(c, SV_ERR_INVALID_ARG, "image %dx%d too small/large for D=%d block=%d", W, H, D, BS);
+    if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63)
+        return fail(c, SV_ERR_UNSUPPORTED, "pre_filter_cap must be in [1,63] (got %d)", p->pre_filter_cap);
+    if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return fail(c, SV_ERR_INVALID_ARG, "need 0 <= P1 <= P2, P2 >= 1");
+    const long cmax = (long)(2 * p->pre_filter_cap + 63) * BS * BS + p->P2;
+    if (cmax > 32767 || (long)p->P1 + 32767 > 65535)
+        return fail(c, SV_ERR_UNSUPPORTED, "cost range overflows int16 (max C = %ld): reduce block_size/P2", cmax);
+    if (p->uniqueness_ratio < 0 || p->uniqueness_ratio > 100)
+        return fail(c, SV_ERR_INVALID_ARG, "uniqueness_ratio must be in [0,100]");
+    if ((p->path_mask & 0xFFu) == 0 || (p->path_mask & ~0xFFu)) return fail(c, SV_ERR_INVALID_ARG, "bad path_mask 0x%x", p->path_mask);
+    if (p->speckle_window_size < 0 || p->speckle_range < 0) return fail(c, SV_ERR_INVALID_ARG, "negative speckle parameter");
+    return SV_OK;
+}
+
+int ensure(sv_ctx* c, Buf& b, size_t bytes) {
+    if (b.n >= bytes && b.p) return SV_OK;
+    if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.n = 0; }
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.n = bytes;
+    return SV_OK;
+}
+void release(Buf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.n = 0;
+}
+
+int alloc_core(sv_ctx* c) {
+    const size_t npx = (size_t)c->W * c->H;
+    const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities;
+    int rc;
+    if ((rc = ensure(c, c->stat_l, npx * 8))) return rc;
+    if ((rc = ensure(c, c->stat_r, npx * 8))) return rc;
+    if ((rc = ensure(c, c->hs, nvol * 2))) return rc;
+    if ((rc = ensure(c, c->C, nvol * 2))) return rc;
+    if ((rc = ensure(c, c->S, nvol * 2))) return rc;
+    if ((rc = ensure(c, c->disp, npx * 2))) return rc;
+    if ((rc = ensure(c, c->raw, npx * 2))) return rc;
+    if ((rc = ensure(c, c->mins, npx * 2))) return rc;
+    if ((rc = ensure(c, c->disp_lr, npx * 2))) return rc;
+    if ((rc = ensure(c, c->out, npx * 2))) return rc;
+    return SV_OK;
+}
+
+struct DevGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess) ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+        else ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <int N>
+void launch_agg_n(sv_ctx* c, int dir, bool first) {
+    static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
+    const int dx = DX[dir], dy = DY[dir];
+    const bool vert = dy != 0;
+    const int nchains = vert ? W1 : H;
+    const dim3 grid((nchains + 3) / 4), block(64);
+    const uint32_t P1P1 = (uint32_t)c->prm.P1 * 0x10001u, P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
+    const uint32_t* Cv = (const uint32_t*)c->C.p;
+    uint32_t* Sv = (uint32_t*)c->S.p;
+    constexpr int U = N <= 4 ? 4 : 2;
+    if (vert) {
+        if (first) hipLaunchKernelGGL((svk::k_agg<N, true, true, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2);
+        else hipLaunchKernelGGL((svk::k_agg<N, true, false, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2);
+    } else {
+        if (first) hipLaunchKernelGGL((svk::k_agg<N, false, true, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2);
+        else hipLaunchKernelGGL((svk::k_agg<N, false, false, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2);
+    }
+}
+
+void launch_agg(sv_ctx* c, int dir, bool first) {
+    switch (c->prm.num_disparities / 32) {
+        case 1: launch_agg_n<1>(c, dir, first); break;
+        case 2: launch_agg_n<2>(c, dir, first); break;
+        case 3: launch_agg_n<3>(c, dir, first); break;
+        case 4: launch_agg_n<4>(c, dir, first); break;
+        case 5: launch_agg_n<5>(c, dir, first); break;
+        case 6: launch_agg_n<6>(c, dir, first); break;
+        case 7: launch_agg_n<7>(c, dir, first); break;
+        default: launch_agg_n<8>(c, dir, first); break;
+    }
+}
+
+template <int N>
+void launch_wta_n(sv_ctx* c) {
+    const size_t npx = (size_t)c->W * c->H;
+    const dim3 grid((unsigned)((npx * 16 + 255) / 256)), block(256);
+    hipLaunchKernelGGL((svk::k_wta<N>), grid, block, 0, c->stream, (const uint32_t*)c->S.p, (int16_t*)c->disp.p,
+                       (int16_t*)c->raw.p, (int16_t*)c->mins.p, c->W, c->H, c->prm.uniqueness_ratio);
+}
+void launch_wta(sv_ctx* c) {
+    switch (c->prm.num_disparities / 32) {
+        case 1: launch_wta_n<1>(c); break;
+        case 2: launch_wta_n<2>(c); break;
+        case 3: launch_wta_n<3>(c); break;
+        case 4: launch_wta_n<4>(c); break;
+        case 5: launch_wta_n<5>(c); break;
+        case 6: launch_wta_n<6>(c); break;
+        case 7: launch_wta_n<7>(c); break;
+        default: launch_wta_n<8>(c); break;
+    }
+}
+
+int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff) {
+    const int n = c->W * c->H;
+    int rc;
+    if ((rc = ensure(c, c->lab, (size_t)n * 4))) return rc;
+    if ((rc = ensure(c, c->cnt, (size_t)n * 4))) return rc;
+    const dim3 b(256), g1((n + 255) / 256), g2((c->W + 255) / 256, c->H);
+    int* lab = (int*)c->lab.p;
+    int* cnt = (int*)c->cnt.p;
+    hipLaunchKernelGGL(svk::k_speckle_init, g1, b, 0, c->stream, img, lab, cnt, n);
+    hipLaunchKernelGGL(svk::k_speckle_merge, g2, b, 0, c->stream, img, lab, c->W, c->H, SV_INVALID_DISP_SCALED, max_diff);
+    hipLaunchKernelGGL(svk::k_speckle_count, g1, b, 0, c->stream, img, lab, cnt, n, SV_INVALID_DISP_SCALED);
+    hipLaunchKernelGGL(svk::k_speckle_apply, g1, b, 0, c->stream, img, lab, cnt, n, SV_INVALID_DISP_SCALED, max_size);
+    HIPCHK(c, hipGetLastError());
+    return SV_OK;
+}
+
+// The matcher proper: device gray pair -> device disparity16.
+int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp16) {
+    const sv_params& p = c->prm;
+    const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
+    const bool tm = c->timing && c->ev_ok;
+    int e = 0;
+    auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[e++], c->stream); };
+    mark();
+    // 1. prefilter + BT statistics
+    hipLaunchKernelGGL(svk::k_stats, dim3((W + 255) / 256, H, 2), dim3(256), 0, c->stream, left, right, (uint2*)c->stat_l.p,
+                       (uint2*)c->stat_r.p, W, H, p.pre_filter_cap);
+    mark();
+    // 2. matching cost volume C
+    {
+        const int ncol = svk::COST_TX + 2 * r;
+        const size_t sm = (size_t)(svk::COST_TX + 10 + 256) * 8 + (size_t)(svk::COST_TX + 10) * 8 + (size_t)ncol * (D / 2) * 4;
+        hipLaunchKernelGGL(svk::k_pix_hsum, dim3((W1 + svk::COST_TX - 1) / svk::COST_TX, H), dim3(256), sm, c->stream,
+                           (const uint2*)c->stat_l.p, (const uint2*)c->stat_r.p, (uint32_t*)c->hs.p, W, H, D, r);
+        const size_t rowN = (size_t)W1 * (D / 2);
+        hipLaunchKernelGGL(svk::k_vsum, dim3((unsigned)((rowN + 255) / 256), (H + svk::VSUM_BAND - 1) / svk::VSUM_BAND), dim3(256),
+                           0, c->stream, (const uint32_t*)c->hs.p, (uint32_t*)c->C.p, W1, H, D, r, (uint32_t)p.P2 * 0x10001u,
+                           (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0);
+    }
+    mark();
+    // 3. path aggregation (first path initialises S)
+    {
+        bool first = true;
+        for (int dir = 0; dir < 8; dir++)
+            if (p.path_mask & (1u << dir)) {
+                launch_agg(c, dir, first);
+                first = false;
+            }
+    }
+    mark();
+    // 4. WTA
+    launch_wta(c);
+    mark();
+    // 5. LR check, median, speckle
+    const int16_t* cur = (const int16_t*)c->disp.p;
+    if (!(p.flags & SV_FLAG_NO_LRCHECK)) {
+        int thr = p.disp12_max_diff;
+        if (p.flags & SV_FLAG_LR_OPENCV) thr = thr > 0 ? thr : 1;
+        hipLaunchKernelGGL(svk::k_lrcheck, dim3(H), dim3(256), (size_t)W * 4, c->stream, cur, (const int16_t*)c->raw.p,
+                           (const int16_t*)c->mins.p, (int16_t*)c->disp_lr.p, W, D, thr);
+        cur = (const int16_t*)c->disp_lr.p;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->disp_lr.p, cur, (size_t)W * H * 2, hipMemcpyDeviceToDevice, c->stream));
+        cur = (const int16_t*)c->disp_lr.p;
+    }
+    if (!(p.flags & SV_FLAG_NO_MEDIAN)) {
+        hipLaunchKernelGGL(svk::k_median3, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, cur, disp16, W, H,
+                           (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
+    } else {
+        HIPCHK(c, hipMemcpyAsync(disp16, cur, (size_t)W * H * 2, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (p.speckle_window_size > 0) {
+        int rc = speckle_dev(c, disp16, p.speckle_window_size, 16 * p.speckle_range);
+        if (rc) return rc;
+    }
+    mark();
+    HIPCHK(c, hipGetLastError());
+    if (tm) {
+        (void)hipEventRecord(c->ev[SV_N_TIMINGS], c->stream);
+        c->ms_valid = true;
+    }
+    return SV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sv_version(void) { return "libsv_hip 0.1 (gfx950)"; }
+
+const char* sv_last_error(const sv_ctx* ctx) { return ctx ? ctx->err : k_noctx; }
+
+int sv_default_params(sv_params* p, int num_disparities, int paths) {
+    if (!p || (paths != 5 && paths != 8)) return SV_ERR_INVALID_ARG;
+    memset(p, 0, sizeof(*p));
+    p->min_disparity = 0;
+    p->num_disparities = num_disparities;
+    p->block_size = 7;
+    p->P1 = 8 * 49;
+    p->P2 = 32 * 49;
+    p->pre_filter_cap = 63;
+    p->uniqueness_ratio = 15;
+    p->disp12_max_diff = 0;
+    p->speckle_window_size = 0;
+    p->speckle_range = 0;
+    p->path_mask = paths == 8 ? SV_PATHS_8 : SV_PATHS_5;
+    p->flags = paths == 8 ? SV_FLAGS_HH : SV_FLAGS_REPO;
+    p->wls_lambda = 4500.0f;
+    p->wls_sigma = 1.0f;
+    return SV_OK;
+}
+
+int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* params) {
+    if (!out) return SV_ERR_INVALID_ARG;
+    *out = nullptr;
+    sv_ctx* c = new (std::nothrow) sv_ctx();
+    if (!c) return SV_ERR_NOMEM;
+    *out = c;  // returned even on failure so the caller can read sv_last_error, then sv_destroy
+    c->device = device;
+    c->W = width;
+    c->H = height;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(c, SV_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(c, SV_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
+    int rc = check_params(c, params, width, height);
+    if (rc) return rc;
+    c->prm = *params;
+    DevGuard g(device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(c, SV_ERR_NO_DEVICE, "device %d is %s; libsv_hip is built for gfx950 only", device, prop.gcnArchName);
+    for (int i = 0; i <= SV_N_TIMINGS; i++) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    c->ev_ok = true;
+    return alloc_core(c);
+}
+
+int sv_destroy(sv_ctx* c) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    {
+        DevGuard g(c->device);
+        if (g.ok) {
+            (void)hipStreamSynchronize(c->stream);
+            Buf* all[] = {&c->img_l, &c->img_r, &c->stat_l, &c->stat_r, &c->hs, &c->C, &c->S, &c->disp, &c->raw, &c->mins,
+                          &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
+                          &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->depth, &c->d16tmp, &c->vis,
+                          &c->lab, &c->cnt};
+            for (Buf* b : all) release(*b);
+            if (c->ev_ok)
+                for (int i = 0; i <= SV_N_TIMINGS; i++) (void)hipEventDestroy(c->ev[i]);
+        }
+    }
+    delete c;
+    return SV_OK;
+}
+
+int sv_set_params(sv_ctx* c, const sv_params* params) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    int rc = check_params(c, params, c->W, c->H);
+    if (rc) return rc;
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    const bool regeom = params->num_disparities != c->prm.num_disparities;
+    if (regeom) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->prm = *params;
+    return regeom ? alloc_core(c) : SV_OK;
+}
+
+int sv_get_params(const sv_ctx* c, sv_params* params) {
+    if (!c || !params) return SV_ERR_INVALID_ARG;
+    *params = c->prm;
+    return SV_OK;
+}
+
+int sv_set_stream(sv_ctx* c, void* hip_stream) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    c->stream = (hipStream_t)hip_stream;
+    return SV_OK;
+}
+
+int sv_compute_gray_dev(sv_ctx* c, const uint8_t* left_dev, const uint8_t* right_dev, int16_t* disp16_dev) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!left_dev || !right_dev || !disp16_dev) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    return run_sgm(c, left_dev, right_dev, disp16_dev);
+}
+
+int sv_compute_gray_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int16_t* disp16, size_t ds) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!left || !right || !disp16) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer");
+    const size_t W = c->W, H = c->H;
+    if (ls < W || rs < W || ds < 2 * W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    int rc;
+    if ((rc = ensure(c, c->img_l, W * H))) return rc;
+    if ((rc = ensure(c, c->img_r, W * H))) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(c->img_l.p, W, left, ls, W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->img_r.p, W, right, rs, W, H, hipMemcpyHostToDevice, c->stream));
+    if ((rc = run_sgm(c, (const uint8_t*)c->img_l.p, (const uint8_t*)c->img_r.p, (int16_t*)c->out.p))) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_gray_from_rgb_dev(sv_ctx* c, const uint8_t* rgb_dev, uint8_t* gray_dev) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!rgb_dev || !gray_dev) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer");
+    DevGuard g(c->device);
+    const size_t n = (size_t)c->W * c->H;
+    hipLaunchKernelGGL(svk::k_gray, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rgb_dev, gray_dev, n);
+    HIPCHK(c, hipGetLastError());
+    return SV_OK;
+}
+
+int sv_upload_maps_host(sv_ctx* c, const float* mlx, const float* mly, const float* mrx, const float* mry) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!mlx || !mly || !mrx || !mry) return fail(c, SV_ERR_INVALID_ARG, "NULL map pointer");
+    DevGuard g(c->device);
+    const size_t bytes = (size_t)c->W * c->H * 4;
+    const float* src[4] = {mlx, mly, mrx, mry};
+    for (int i = 0; i < 4; i++) {
+        int rc = ensure(c, c->maps[i], bytes);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->maps[i].p, src[i], bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_maps = true;
+    return SV_OK;
+}
+
+int sv_remap_rgb_dev(sv_ctx* c, int which, const uint8_t* src, uint8_t* dst) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!src || !dst || which < 0 || which > 1) return fail(c, SV_ERR_INVALID_ARG, "bad remap argument");
+    if (!c->have_maps) return fail(c, SV_ERR_NO_MAPS, "rectification maps not uploaded (sv_upload_maps_host)");
+    DevGuard g(c->device);
+    hipLaunchKernelGGL(svk::k_remap_rgb, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream, src, dst,
+                       (const float*)c->maps[2 * which].p, (const float*)c->maps[2 * which + 1].p, c->W, c->H);
+    HIPCHK(c, hipGetLastError());
+    return SV_OK;
+}
+
+int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int rectify,
+                        int16_t* disp16, size_t ds) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!left || !right || !disp16) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer");
+    const size_t W = c->W, H = c->H;
+    if (ls < 3 * W || rs < 3 * W || ds < 2 * W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    if (rectify && !c->have_maps) return fail(c, SV_ERR_NO_MAPS, "rectification maps not uploaded (sv_upload_maps_host)");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    int rc;
+    Buf* need3[] = {&c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r};
+    for (Buf* b : need3)
+        if ((rc = ensure(c, *b, W * H * 3))) return rc;
+    if ((rc = ensure(c, c->gray_l, W * H))) return rc;
+    if ((rc = ensure(c, c->gray_r, W * H))) return rc;
+    Buf& dl = rectify ? c->rgb_l : c->rect_l;
+    Buf& dr = rectify ? c->rgb_r : c->rect_r;
+    HIPCHK(c, hipMemcpy2DAsync(dl.p, 3 * W, left, ls, 3 * W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(dr.p, 3 * W, right, rs, 3 * W, H, hipMemcpyHostToDevice, c->stream));
+    if (rectify) {
+        if ((rc = sv_remap_rgb_dev(c, 0, (const uint8_t*)c->rgb_l.p, (uint8_t*)c->rect_l.p))) return rc;
+        if ((rc = sv_remap_rgb_dev(c, 1, (const uint8_t*)c->rgb_r.p, (uint8_t*)c->rect_r.p))) return rc;
+    }
+    if ((rc = sv_gray_from_rgb_dev(c, (const uint8_t*)c->rect_l.p, (uint8_t*)c->gray_l.p))) return rc;
+    if ((rc = sv_gray_from_rgb_dev(c, (const uint8_t*)c->rect_r.p, (uint8_t*)c->gray_r.p))) return rc;
+    if ((rc = run_sgm(c, (const uint8_t*)c->gray_l.p, (const uint8_t*)c->gray_r.p, (int16_t*)c->out.p))) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_get_rectified_host(sv_ctx* c, int which, uint8_t* rgb, size_t stride) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    const size_t W = c->W, H = c->H;
+    Buf& b = which ? c->rect_r : c->rect_l;
+    if (!rgb || stride < 3 * W || which < 0 || which > 1) return fail(c, SV_ERR_INVALID_ARG, "bad argument");
+    if (!b.p) return fail(c, SV_ERR_INVALID_ARG, "no rectified image yet (call sv_compute_rgb_host first)");
+    DevGuard g(c->device);
+    HIPCHK(c, hipMemcpy2DAsync(rgb, stride, b.p, 3 * W, 3 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_disparity_vis_dev(sv_ctx* c, const int16_t* d16, uint8_t* vis, int scale) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !vis) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    DevGuard g(c->device);
+    const size_t n = (size_t)c->W * c->H;
+    hipLaunchKernelGGL(svk::k_vis, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d16, vis, n, scale);
+    HIPCHK(c, hipGetLastError());
+    return SV_OK;
+}
+
+int sv_disparity_vis_host(sv_ctx* c, const int16_t* d16, uint8_t* vis, int scale) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !vis) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    DevGuard g(c->device);
+    const size_t n = (size_t)c->W * c->H;
+    int rc;
+    if ((rc = ensure(c, c->d16tmp, n * 2))) return rc;
+    if ((rc = ensure(c, c->vis, n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d16tmp.p, d16, n * 2, hipMemcpyHostToDevice, c->stream));
+    if ((rc = sv_disparity_vis_dev(c, (const int16_t*)c->d16tmp.p, (uint8_t*)c->vis.p, scale))) return rc;
+    HIPCHK(c, hipMemcpyAsync(vis, c->vis.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_filter_speckles_dev(sv_ctx* c, int16_t* d16, int max_size, int max_diff) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || max_size < 0 || max_diff < 0) return fail(c, SV_ERR_INVALID_ARG, "bad speckle argument");
+    DevGuard g(c->device);
+    return speckle_dev(c, d16, max_size, max_diff);
+}
+
+int sv_depth_dev(sv_ctx* c, const int16_t* d16, const float* mapper, const double* Q, const double* R, float* depth) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !mapper || !Q || !R || !depth) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    DevGuard g(c->device);
+    svk::DepthCoef k;
+    k.r02 = (float)R[2]; k.r12 = (float)R[5]; k.r22 = (float)R[8];
+    k.q00 = (float)Q[0]; k.q03 = (float)Q[3]; k.q11 = (float)Q[5]; k.q13 = (float)Q[7];
+    k.q23 = (float)Q[11]; k.q32 = (float)Q[14]; k.q33 = (float)Q[15];
+    hipLaunchKernelGGL(svk::k_depth, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream, d16, (const float2*)mapper, depth,
+                       c->W, c->H, k);
+    HIPCHK(c, hipGetLastError());
+    return SV_OK;
+}
+
+int sv_depth_host(sv_ctx* c, const int16_t* d16, size_t dstride, const float* mapper, const double* Q, const double* R,
+                  float* depth, size_t ostride) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !mapper || !Q || !R || !depth) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    const size_t W = c->W, H = c->H;
+    if (dstride < 2 * W || ostride < 4 * W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    DevGuard g(c->device);
+    int rc;
+    if ((rc = ensure(c, c->d16tmp, W * H * 2))) return rc;
+    if ((rc = ensure(c, c->mapper, W * H * 8))) return rc;
+    if ((rc = ensure(c, c->depth, W * H * 4))) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(c->d16tmp.p, 2 * W, d16, dstride, 2 * W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->mapper.p, mapper, W * H * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = sv_depth_dev(c, (const int16_t*)c->d16tmp.p, (const float*)c->mapper.p, Q, R, (float*)c->depth.p))) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(depth, ostride, c->depth.p, 4 * W, 4 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_debug_read_volume_host(sv_ctx* c, int which, int16_t* vol, size_t n_elems) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities;
+    if (!vol || n_elems != nvol || which < 0 || which > 1) return fail(c, SV_ERR_INVALID_ARG, "bad volume request");
+    DevGuard g(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(vol, which ? c->S.p : c->C.p, nvol * 2, hipMemcpyDeviceToHost));
+    return SV_OK;
+}
+
+int sv_debug_read_plane_host(sv_ctx* c, int which, int16_t* plane) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!plane || which < 0 || which > 3) return fail(c, SV_ERR_INVALID_ARG, "bad plane request");
+    Buf* src[4] = {&c->disp, &c->raw, &c->mins, &c->disp_lr};
+    DevGuard g(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(plane, src[which]->p, (size_t)c->W * c->H * 2, hipMemcpyDeviceToHost));
+    return SV_OK;
+}
+
+int sv_enable_timing(sv_ctx* c, int enable) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    c->timing = enable != 0;
+    c->ms_valid = false;
+    return SV_OK;
+}
+
+int sv_get_timings(sv_ctx* c, float* ms, int n) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!ms || n < SV_N_TIMINGS) return fail(c, SV_ERR_INVALID_ARG, "need room for %d timings", SV_N_TIMINGS);
+    if (!c->ms_valid) return fail(c, SV_ERR_INVALID_ARG, "no timed frame yet (sv_enable_timing, then compute)");
+    DevGuard g(c->device);
+    HIPCHK(c, hipEventSynchronize(c->ev[SV_N_TIMINGS]));
+    // events: 0 start, 1 after stats, 2 after cost, 3 after agg, 4 after wta, 5 after tail
+    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
+    return SV_OK;
+}
+
+int64_t sv_algorithmic_bytes(const sv_ctx* c, int which) {
+    if (!c) return -1;
+    const int64_t W = c->W, H = c->H, D = c->prm.num_disparities;
+    const int64_t V = (W - D) * H * D * 2;
+    int64_t P = 0;
+    for (int i = 0; i < 8; i++) P += (c->prm.path_mask >> i) & 1;
+    switch (which) {
+        case 0: return V + 2 * W * H;
+        case 1: return 3 * P * V;
+        case 2: return V + 6 * W * H;
+        case 3: return 8 * W * H;
+        case 4: return (3 * P + 2) * V + 16 * W * H;
+        default: return -1;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,593 @@
+// sv_kernels.hip.h — hand-written gfx950 (CDNA4, wave64) kernels of libsv_hip.
+//
+// Each kernel names the reference code whose RESULT it reproduces (paths relative to
+// /root/reference/modules/DisparityModule/).  None of them follows the reference's launch
+// shapes: the CUDA back-end runs one 32-thread warp per scanline with the previous L in shared
+// memory and a device-wide sync after every launch (sgbm_cuda/bova_sgm.cu:91-134); here a
+// scanline lives in 16 lanes of a wave64 (four scanlines per wave), previous-L stays in VGPRs as
+// packed u16 pairs, neighbours move with DPP row shifts and the per-pixel minimum is a 4-step DPP
+// butterfly, so a step never touches LDS or a barrier.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svk {
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, 0xf, false);
+}
+// DPP controls (gfx9): within a 16-lane row.
+constexpr int DPP_QUAD_XOR1 = 0xB1;  // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_SHL1 = 0x101;  // lane i <- lane i+1
+constexpr int DPP_ROW_SHR1 = 0x111;  // lane i <- lane i-1
+constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+
+// all-lanes reduction over a 16-lane row (every lane ends with the result)
+__device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
+    v = min(v, dpp<DPP_QUAD_XOR1>(v, v));
+    v = min(v, dpp<DPP_QUAD_XOR2>(v, v));
+    v = min(v, dpp<DPP_ROW_HALF_MIRROR>(v, v));
+    v = min(v, dpp<DPP_ROW_MIRROR>(v, v));
+    return v;
+}
+__device__ __forceinline__ uint32_t row16_or_u32(uint32_t v) {
+    v |= dpp<DPP_QUAD_XOR1>(v, v);
+    v |= dpp<DPP_QUAD_XOR2>(v, v);
+    v |= dpp<DPP_ROW_HALF_MIRROR>(v, v);
+    v |= dpp<DPP_ROW_MIRROR>(v, v);
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void load_regs(const uint32_t* __restrict__ p, uint32_t (&r)[N]) {
+    if constexpr (N == 1) {
+        r[0] = p[0];
+    } else if constexpr (N == 2) {
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+        r[0] = v.x; r[1] = v.y;
+    } else if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 4; i++) {
+            uint4 v = reinterpret_cast<const uint4*>(p)[i];
+            r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+        }
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 2; i++) {
+            uint2 v = reinterpret_cast<const uint2*>(p)[i];
+            r[2 * i] = v.x; r[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) r[i] = p[i];
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_regs(uint32_t* __restrict__ p, const uint32_t (&r)[N]) {
+    if constexpr (N == 1) {
+        p[0] = r[0];
+    } else if constexpr (N == 2) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(r[0], r[1]);
+    } else if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 4; i++)
+            reinterpret_cast<uint4*>(p)[i] = make_uint4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 2; i++) reinterpret_cast<uint2*>(p)[i] = make_uint2(r[2 * i], r[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) p[i] = r[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 1: prefilter + Birchfield-Tomasi interval statistics.
+// Result of get_gradient (sgbm_cuda/costs.cu:116-166, clip table :286-292) followed by the
+// per-pixel half-sample min/max that get_pixel_diff recomputes for every disparity
+// (costs.cu:180-193).  One 8-byte record per pixel: {g, g0, g1, r, r0, r1, 0, 0} where g is the
+// clipped Sobel-x value, r the raw channel with its edge columns forced to ftzero, and a0/a1 the
+// min/max of {a, (a+left)/2, (a+right)/2}.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int grad_at(const uint8_t* __restrict__ img, int W, int H, int x, int y, int cap) {
+    if (x <= 0 || x >= W - 1) return cap;
+    const uint8_t* r0 = img + (size_t)y * W;
+    const uint8_t* rm = img + (size_t)max(y - 1, 0) * W;
+    const uint8_t* rp = img + (size_t)min(y + 1, H - 1) * W;
+    int v = ((int)r0[x + 1] - (int)r0[x - 1]) * 2 + (int)rm[x + 1] - (int)rm[x - 1] + (int)rp[x + 1] - (int)rp[x - 1];
+    return min(max(v, -cap), cap) + cap;
+}
+__device__ __forceinline__ int raw_at(const uint8_t* __restrict__ img, int W, int x, int y, int cap) {
+    if (x <= 0 || x >= W - 1) return cap;
+    return img[(size_t)y * W + x];
+}
+
+__global__ __launch_bounds__(256) void k_stats(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                uint2* __restrict__ stat_l, uint2* __restrict__ stat_r, int W, int H,
+                                                int cap) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t* img = blockIdx.z ? right : left;
+    uint2* out = blockIdx.z ? stat_r : stat_l;
+    int g = grad_at(img, W, H, x, y, cap), r = raw_at(img, W, x, y, cap);
+    int gl = x > 0 ? (g + grad_at(img, W, H, x - 1, y, cap)) / 2 : g;
+    int gr = x < W - 1 ? (g + grad_at(img, W, H, x + 1, y, cap)) / 2 : g;
+    int rl = x > 0 ? (r + raw_at(img, W, x - 1, y, cap)) / 2 : r;
+    int rr = x < W - 1 ? (r + raw_at(img, W, x + 1, y, cap)) / 2 : r;
+    int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
+    int r0 = min(min(rl, rr), r), r1 = max(max(rl, rr), r);
+    out[(size_t)y * W + x] = make_uint2((uint32_t)g | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r << 24),
+                                        (uint32_t)r0 | ((uint32_t)r1 << 8));
+}
+
+// BT cost of one (left pixel, right pixel) pair over both channels (costs.cu:180-199).
+__device__ __forceinline__ uint32_t bt_pair(uint2 l, uint2 r) {
+    int u = l.x & 0xff, u0 = (l.x >> 8) & 0xff, u1 = (l.x >> 16) & 0xff;
+    int v = r.x & 0xff, v0 = (r.x >> 8) & 0xff, v1 = (r.x >> 16) & 0xff;
+    int c0 = max(max(0, u - v1), v0 - u), c1 = max(max(0, v - u1), u0 - v);
+    int cost = min(c0, c1);
+    u = l.x >> 24; u0 = l.y & 0xff; u1 = (l.y >> 8) & 0xff;
+    v = r.x >> 24; v0 = r.y & 0xff; v1 = (r.y >> 8) & 0xff;
+    c0 = max(max(0, u - v1), v0 - u); c1 = max(max(0, v - u1), u0 - v);
+    return (uint32_t)(cost + (min(c0, c1) >> 2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2a: pixel cost + horizontal box sum, one (row, 32-column tile) per workgroup.
+// Result of get_pixel_diff x2 + get_hsum (costs.cu:170-233) without materialising pixDiff: the BT
+// costs of the tile plus its halo are built in LDS as packed u16 pairs and summed from there.
+// hs layout: [H][W1][D] u16, d innermost (same order as the reference volumes, common.h:23-25).
+// ---------------------------------------------------------------------------------------------
+constexpr int COST_TX = 32;
+__global__ __launch_bounds__(256) void k_pix_hsum(const uint2* __restrict__ stat_l, const uint2* __restrict__ stat_r,
+                                                   uint32_t* __restrict__ hs, int W, int H, int D, int radius) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    const int W1 = W - D, D2 = D >> 1;
+    const int xl0 = blockIdx.x * COST_TX, y = blockIdx.y;
+    const int ncol = COST_TX + 2 * radius;
+    // R records for x in [rbase, rbase + nr)
+    const int xl_first = max(xl0 - radius, 0), xl_last = min(xl0 + COST_TX - 1 + radius, W1 - 1);
+    const int rbase = xl_first + 1;  // = (xl_first + D) - (D - 1)
+    const int nr = xl_last + D - rbase + 1;
+    uint2* Rs = reinterpret_cast<uint2*>(smem);
+    uint2* Ls = Rs + (COST_TX + 2 * 5 + 256);
+    uint32_t* pix = reinterpret_cast<uint32_t*>(Ls + (COST_TX + 2 * 5));  // [ncol][D2]
+    const uint2* lrow = stat_l + (size_t)y * W;
+    const uint2* rrow = stat_r + (size_t)y * W;
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) Rs[i] = rrow[rbase + i];
+    for (int j = threadIdx.x; j < ncol; j += blockDim.x) {
+        int xl = min(max(xl0 - radius + j, 0), W1 - 1);
+        Ls[j] = lrow[xl + D];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < ncol * D2; it += blockDim.x) {
+        int j = it / D2, dq = it - j * D2;
+        int xl = min(max(xl0 - radius + j, 0), W1 - 1);
+        int xr = xl + D - 2 * dq - rbase;  // index of x - d for d = 2*dq
+        uint2 l = Ls[j];
+        uint32_t a = bt_pair(l, Rs[xr]);
+        uint32_t b = bt_pair(l, Rs[xr - 1]);
+        pix[it] = a | (b << 16);
+    }
+    __syncthreads();
+    const int nwin = 2 * radius + 1;
+    for (int it = threadIdx.x; it < COST_TX * D2; it += blockDim.x) {
+        int xi = it / D2, dq = it - xi * D2;
+        int xl = xl0 + xi;
+        if (xl >= W1) break;
+        uint32_t acc = 0;  // packed halves cannot carry: 189 * 11 < 65536
+        for (int k = 0; k < nwin; k++) acc += pix[(xi + k) * D2 + dq];
+        hs[((size_t)y * W1 + xl) * D2 + dq] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2b: vertical box sum + P2.  Result of get_cost (costs.cu:235-284) written as the clamped
+// window sum it equals when no int16 store wraps (guaranteed by sv_check_params), with the two
+// quirks kept: column x = D repeats row 0 (:254-267) and the bottom SH2 rows repeat the last
+// computed row (:279-282); the SV_FLAG_C_*_P2 flags select the MODE_HH alternatives.
+// One thread owns one packed (xl, d-pair) and marches down a band of rows with a running sum.
+// ---------------------------------------------------------------------------------------------
+constexpr int VSUM_BAND = 32;
+__global__ __launch_bounds__(256) void k_vsum(const uint32_t* __restrict__ hs, uint32_t* __restrict__ C, int W1, int H,
+                                               int D, int radius, uint32_t P2P2, int col0_p2, int tail_p2) {
+    const int D2 = D >> 1;
+    const size_t rowN = (size_t)W1 * D2;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rowN) return;
+    const int y0 = blockIdx.y * VSUM_BAND, y1 = min(y0 + VSUM_BAND, H);
+    const int ylast = H - 1 - radius;
+    const bool col0 = e < (size_t)D2;
+    const int ys = min(y0, ylast);
+    uint32_t acc = 0;
+    for (int k = -radius; k <= radius; k++) acc += hs[(size_t)max(ys + k, 0) * rowN + e];
+    uint32_t row0 = 0;
+    if (col0) {
+        for (int k = -radius; k <= radius; k++) row0 += hs[(size_t)max(k, 0) * rowN + e];
+        row0 += P2P2;
+    }
+    for (int y = y0; y < y1; y++) {
+        uint32_t val;
+        if (y <= ylast) {
+            if (y > ys) acc = acc + hs[(size_t)(y + radius) * rowN + e] - hs[(size_t)max(y - radius - 1, 0) * rowN + e];
+            val = acc + P2P2;
+        } else {
+            val = tail_p2 ? P2P2 : acc + P2P2;
+        }
+        if (col0 && y > 0) val = col0_p2 ? P2P2 : row0;
+        C[(size_t)y * rowN + e] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 3: one SGM path.  Result of cost_aggregation_{lr,ud_lr,ud,rl_ud,rl}
+// (sgbm_cuda/aggregation.cu:60-625) and, with dy = -1, of the second sweep of MODE_HH:
+//   L(p,d) = C(p,d) + min(Lp(d), Lp(d-1)+P1, Lp(d+1)+P1, delta) - delta,  delta = min_d Lp + P2,
+//   S(p,d) = min(S(p,d) + L(p,d), 32767)            (safe_add, aggregation.cu:4-10)
+// A scanline ("chain") is 16 lanes; lane q holds disparities [q*2N, (q+1)*2N) as N packed u16
+// pairs.  Horizontal paths: chain = image row.  Vertical / diagonal paths: chain = start column
+// c, pixel at step i is (y_i, (c + dx*i) mod W1); when the column wraps the path restarts fresh
+// (Lp = 0, delta = P2) exactly as the reference's diagonal kernels do at the image edge
+// (aggregation.cu:233-256, :469-492) — and unlike them every pixel is visited for any aspect ratio.
+// FIRST = this path initialises S (no read, no memset: bova_sgm.cu:106 is not needed).
+// ---------------------------------------------------------------------------------------------
+template <int N, int U>
+struct AggBatch {
+    uint32_t c[U][N], s[U][N];
+    size_t off[U];
+    uint32_t rst;  // bit j: step j of the batch starts a fresh path; bit U: step 0 of the next batch does
+};
+
+template <int N, bool VERT, bool FIRST, int U>
+__global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, int W1, int H, int dx,
+                                             int dy, uint32_t P1P1, uint32_t P2P2) {
+    const int q = threadIdx.x & 15;
+    const int nchains = VERT ? W1 : H, nsteps = VERT ? H : W1;
+    int chain = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    const bool valid = chain < nchains;
+    chain = min(chain, nchains - 1);
+    const size_t pxN = (size_t)16 * N;  // u32 per pixel
+    const uint32_t laneoff = (uint32_t)q * N;
+
+    // load cursor (runs one batch ahead of the compute)
+    int lx, ly;
+    if (VERT) { lx = chain; ly = dy > 0 ? 0 : H - 1; }
+    else      { ly = chain; lx = dx > 0 ? 0 : W1 - 1; }
+
+    auto issue = [&](int i0, AggBatch<N, U>& b) {
+        b.rst = 0;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            if (i0 + j < nsteps) {
+                b.off[j] = ((size_t)ly * W1 + lx) * pxN + laneoff;
+                load_regs<N>(C + b.off[j], b.c[j]);
+                if (!FIRST) load_regs<N>(S + b.off[j], b.s[j]);
+                if (VERT) {
+                    ly += dy;
+                    lx += dx;
+                    if (lx >= W1) { lx = 0; b.rst |= 2u << j; }
+                    if (lx < 0) { lx = W1 - 1; b.rst |= 2u << j; }
+                } else {
+                    lx += dx;
+                }
+            }
+        }
+    };
+
+    uint32_t r[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = 0;
+    uint32_t dd = P2P2;
+    uint32_t carry = 0;  // fresh-start flag for step 0 of the next batch
+
+    auto compute = [&](int i0, AggBatch<N, U>& b) {
+        const uint32_t flags = b.rst | carry;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            if (i0 + j < nsteps) {
+                if (VERT && ((flags >> j) & 1u)) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) r[k] = 0;
+                    dd = P2P2;
+                }
+                const uint32_t prevHi = dpp<DPP_ROW_SHR1>(0x7FFF7FFFu, r[N - 1]);
+                const uint32_t nextLo = dpp<DPP_ROW_SHL1>(0x7FFF7FFFu, r[0]);
+                uint32_t m[N + 1];
+                m[0] = __builtin_amdgcn_alignbit(r[0], prevHi, 16);
+#pragma unroll
+                for (int k = 1; k < N; k++) m[k] = __builtin_amdgcn_alignbit(r[k], r[k - 1], 16);
+                m[N] = __builtin_amdgcn_alignbit(nextLo, r[N - 1], 16);
+                uint32_t mn = 0xFFFFFFFFu;
+                uint32_t snew[N];
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    uint32_t t = pk_add(pk_min(m[k], m[k + 1]), P1P1);
+                    t = pk_min(pk_min(t, r[k]), dd);
+                    uint32_t L = pk_sub(pk_add(b.c[j][k], t), dd);
+                    r[k] = L;
+                    mn = pk_min(mn, L);
+                    snew[k] = FIRST ? L : pk_min(pk_add(b.s[j][k], L), 0x7FFF7FFFu);
+                }
+                mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // both halves = lane minimum
+                mn = row16_min_u32(mn);
+                dd = mn + P2P2;  // halves cannot carry: min + P2 < 65536
+                if (valid) store_regs<N>(S + b.off[j], snew);
+            }
+        }
+        carry = (b.rst >> U) & 1u;
+    };
+
+    AggBatch<N, U> A, B;
+    issue(0, A);
+    for (int i0 = 0; i0 < nsteps; i0 += 2 * U) {
+        issue(i0 + U, B);
+        compute(i0, A);
+        issue(i0 + 2 * U, A);
+        compute(i0 + U, B);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 4: winner-take-all + uniqueness + sub-pixel.  Result of get_disparity
+// (aggregation.cu:629-689).  16 lanes per pixel (same register layout as k_agg), full image width:
+// columns [0, D) get the contract value -16 (the reference leaves them uninitialised).
+// raw = -1 marks "no disparity" (reference: INVALID_DISP_SCALED in d_raw_disp, :642).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, int16_t* __restrict__ disp,
+                                              int16_t* __restrict__ raw, int16_t* __restrict__ mins, int W, int H, int uniq) {
+    const int D = 32 * N, W1 = W - D;
+    const int q = threadIdx.x & 15;
+    const size_t pid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const size_t npx = (size_t)W * H;
+    const bool inimg = pid < npx;
+    const size_t p = inimg ? pid : npx - 1;
+    const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+    const int xl = max(x - D, 0);
+    uint32_t s[N];
+    load_regs<N>(S + ((size_t)y * W1 + xl) * 16 * N + q * N, s);
+    const int dbase = q * 2 * N;
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        key = min(key, ((s[k] & 0xFFFFu) << 16) | (uint32_t)(dbase + 2 * k));
+        key = min(key, (s[k] & 0xFFFF0000u) | (uint32_t)(dbase + 2 * k + 1));
+    }
+    key = row16_min_u32(key);
+    const int minS = (int)(key >> 16), best = (int)(key & 0xFFFFu);
+    uint32_t bad = 0, nb = 0;
+    const int thr = minS * 100, mul = 100 - uniq;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            int d = dbase + 2 * k + h;
+            int v = (int)(h ? (s[k] >> 16) : (s[k] & 0xFFFFu));
+            if (v * mul < thr && abs(best - d) > 1) bad = 1;
+            if (d == best - 1) nb |= (uint32_t)v << 16;
+            if (d == best + 1) nb |= (uint32_t)v;
+        }
+    }
+    bad = row16_or_u32(bad);
+    nb = row16_or_u32(nb);
+    if (q == 0 && inimg) {
+        int dv = -16, rw = -1, mv = 32767;
+        if (x >= D) {
+            mv = minS;
+            if (minS < 32767 && !bad) {
+                rw = best;
+                if (0 < best && best < D - 1) {
+                    int sm = (int)(nb >> 16), sp = (int)(nb & 0xFFFFu);
+                    int denom2 = max(sm + sp - 2 * minS, 1);
+                    dv = best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
+                } else
+                    dv = best * 16;
+            }
+        }
+        disp[p] = (int16_t)dv;
+        raw[p] = (int16_t)rw;
+        mins[p] = (int16_t)mv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 5: left-right check, one workgroup per image row.  Result of lrcheck
+// (aggregation.cu:691-735): disp2/disp2cost are built right-to-left with a strict '>' (ties keep
+// the larger x); the same winner is the minimum of the packed key (cost << 16 | 0xFFFF - x), so an
+// LDS atomicMin reproduces it without the serial scan.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ disp, const int16_t* __restrict__ raw,
+                                                  const int16_t* __restrict__ mins, int16_t* __restrict__ out, int W, int D,
+                                                  int thresh) {
+    extern __shared__ uint32_t keys[];
+    const int y = blockIdx.x;
+    const int16_t* dp = disp + (size_t)y * W;
+    const int16_t* rw = raw + (size_t)y * W;
+    const int16_t* mn = mins + (size_t)y * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) keys[x] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int x = D + threadIdx.x; x < W; x += blockDim.x) {
+        int d = rw[x];
+        if (d >= 0) atomicMin(&keys[x - d], ((uint32_t)(uint16_t)mn[x] << 16) | (uint32_t)(0xFFFF - x));
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        int d1 = dp[x];
+        if (x >= D && d1 != -16) {
+            int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+            int _x = x - _d, x_ = x - d_;
+            bool f1 = false, f2 = false;
+            if (0 <= _x && _x < W) {
+                uint32_t k = keys[_x];
+                if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - _x; f1 = abs(d2 - _d) > thresh; }
+            }
+            if (0 <= x_ && x_ < W) {
+                uint32_t k = keys[x_];
+                if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - x_; f2 = abs(d2 - d_) > thresh; }
+            }
+            if (f1 && f2) d1 = -16;
+        }
+        out[(size_t)y * W + x] = (int16_t)d1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 6: 3x3 median.  Result of MedianFilter (aggregation.cu:737-768); replicate = 1 gives
+// cv::medianBlur's border handling instead of copying the border.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(int& a, int& b) { int t = min(a, b); b = max(a, b); a = t; }
+__global__ __launch_bounds__(256) void k_median3(const int16_t* __restrict__ in, int16_t* __restrict__ out, int W, int H,
+                                                  int replicate) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const bool border = (x < 1 || y < 1 || x >= W - 1 || y >= H - 1);
+    if (border && !replicate) { out[(size_t)y * W + x] = in[(size_t)y * W + x]; return; }
+    int v[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            int yy = min(max(y + i - 1, 0), H - 1), xx = min(max(x + j - 1, 0), W - 1);
+            v[i * 3 + j] = in[(size_t)yy * W + xx];
+        }
+    // median-of-9 exchange network
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+    cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
+    cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+    cswap(v[4], v[2]);
+    out[(size_t)y * W + x] = (int16_t)v[4];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Speckle filter.  Result of cv::filterSpeckles (inside cv::StereoSGBM::compute, which matchSGBM
+// calls, StereoMatcher.cpp:412): 4-connected components of pixels != newVal joined when
+// |delta| <= maxDiff; components of size <= maxSize become newVal.  Union-find in global memory
+// (label = smallest pixel index of the component), so the result is order-independent.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uf_find(int* __restrict__ lab, int a) {
+    int p = lab[a];
+    while (p != a) { a = p; p = lab[a]; }
+    return a;
+}
+__device__ __forceinline__ void uf_union(int* __restrict__ lab, int a, int b) {
+    while (true) {
+        a = uf_find(lab, a);
+        b = uf_find(lab, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&lab[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+__global__ __launch_bounds__(256) void k_speckle_init(const int16_t* __restrict__ img, int* __restrict__ lab,
+                                                       int* __restrict__ cnt, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { lab[i] = i; cnt[i] = 0; }
+}
+__global__ __launch_bounds__(256) void k_speckle_merge(const int16_t* __restrict__ img, int* __restrict__ lab, int W, int H,
+                                                        int new_val, int max_diff) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    int i = y * W + x, v = img[i];
+    if (v == new_val) return;
+    if (x + 1 < W) { int u = img[i + 1]; if (u != new_val && abs(u - v) <= max_diff) uf_union(lab, i, i + 1); }
+    if (y + 1 < H) { int u = img[i + W]; if (u != new_val && abs(u - v) <= max_diff) uf_union(lab, i, i + W); }
+}
+__global__ __launch_bounds__(256) void k_speckle_count(const int16_t* __restrict__ img, int* __restrict__ lab,
+                                                        int* __restrict__ cnt, int n, int new_val) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || img[i] == new_val) return;
+    int r = uf_find(lab, i);
+    lab[i] = r;  // path compression: only ever lowers a label towards its root
+    atomicAdd(&cnt[r], 1);
+}
+__global__ __launch_bounds__(256) void k_speckle_apply(int16_t* __restrict__ img, const int* __restrict__ lab,
+                                                        const int* __restrict__ cnt, int n, int new_val, int max_size) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || img[i] == new_val) return;
+    int r = lab[i];
+    while (lab[r] != r) r = lab[r];
+    if (cnt[r] <= max_size) img[i] = (int16_t)new_val;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-pixel helpers around the matcher.
+// ---------------------------------------------------------------------------------------------
+// cv::cvtColor(CV_BGR2GRAY) on RGB-ordered bytes (StereoMatcher.cpp:429-430).
+__global__ __launch_bounds__(256) void k_gray(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ gray, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t a = rgb[3 * i], b = rgb[3 * i + 1], c = rgb[3 * i + 2];
+    gray[i] = (uint8_t)((a * 1868u + b * 9617u + c * 4899u + (1u << 13)) >> 14);
+}
+// cv::ximgproc::getDisparityVis (StereoMatcher.cpp:437).
+__global__ __launch_bounds__(256) void k_vis(const int16_t* __restrict__ d16, uint8_t* __restrict__ vis, size_t n, int scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int v = (int)d16[i] * scale;
+    int qv = v >> 4, r = v & 15;
+    if (r > 8 || (r == 8 && (qv & 1))) qv++;
+    vis[i] = (uint8_t)min(max(qv, 0), 255);
+}
+// cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) on 8UC3 (stereoCamera.cpp:573-574): a gather with
+// coalesced destination rows; the source neighbourhood of a row is a narrow band, served by L2.
+__global__ __launch_bounds__(256) void k_remap_rgb(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                    const float* __restrict__ mapx, const float* __restrict__ mapy, int W,
+                                                    int H) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t o = (size_t)y * W + x;
+    float fxm = fminf(fmaxf(mapx[o] * 32.0f, -1.0e9f), 1.0e9f);
+    float fym = fminf(fmaxf(mapy[o] * 32.0f, -1.0e9f), 1.0e9f);
+    int sx = __float2int_rn(fxm), sy = __float2int_rn(fym);
+    int ix = min(max(sx >> 5, -32768), 32767), iy = min(max(sy >> 5, -32768), 32767);
+    int fx = sx & 31, fy = sy & 31;
+    int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W, y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+    const uint8_t* p00 = src + ((size_t)iy * W + ix) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int a = (y0 && x0) ? p00[c] : 0, b = (y0 && x1) ? p00[3 + c] : 0;
+        int e = (y1 && x0) ? p00[(size_t)W * 3 + c] : 0, f = (y1 && x1) ? p00[(size_t)W * 3 + 3 + c] : 0;
+        int v = (a * w00 + b * w01 + e * w10 + f * w11 + (1 << 14)) >> 15;
+        dst[o * 3 + c] = (uint8_t)min(v, 255);
+    }
+}
+// DispModule::depthFromDisparity (DispModule.cpp:320-366), non-aliased read.
+struct DepthCoef { float r02, r12, r22, q00, q03, q11, q13, q23, q32, q33; };
+__global__ __launch_bounds__(256) void k_depth(const int16_t* __restrict__ d16, const float2* __restrict__ mapper,
+                                                float* __restrict__ depth, int W, int H, DepthCoef c) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+    if (v >= W) return;
+    const size_t o = (size_t)u * W + v;
+    float2 m = mapper[o];
+    float usign = rintf(m.x), vsign = rintf(m.y);
+    float out = 0.0f;
+    if (!(usign < 0 || usign >= (float)W || vsign < 0 || vsign >= (float)H)) {
+        float dsp = (float)d16[(size_t)vsign * W + (size_t)usign] * 0.0625f;
+        float num = c.r02 * (vsign * c.q00 + c.q03) + c.r12 * (usign * c.q11 + c.q13) + c.r22 * c.q23;
+        out = num / (dsp * c.q32 + c.q33);
+    }
+    depth[o] = out;
+}
+
+}  // namespace svk

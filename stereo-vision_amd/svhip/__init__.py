@@ -1,0 +1,232 @@
+"""svhip — Python plumbing over the libsv_hip C ABI (include/sv_hip.h).
+
+The product is libsv_hip.so (hand-written gfx950 kernels behind a C ABI) plus the
+C++ host shim in ../host; this module only binds the ABI with ctypes so that the
+parity tests and bench.py can drive it, and so that PyTorch can own device
+memory and streams.  There is NO CPU fallback: if the shared library is missing
+or no gfx950 device is present, every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libsv_hip.so")
+
+INVALID = -16
+PATH_R, PATH_DR, PATH_D, PATH_DL, PATH_L, PATH_UL, PATH_U, PATH_UR = (1 << i for i in range(8))
+PATHS_5, PATHS_8 = 0x1F, 0xFF
+FLAG_C_COL0_P2, FLAG_C_TAIL_P2, FLAG_LR_OPENCV, FLAG_MEDIAN_REPLICATE = 1, 2, 4, 8
+FLAG_NO_LRCHECK, FLAG_NO_MEDIAN = 0x10, 0x20
+FLAGS_REPO = 0
+FLAGS_HH = FLAG_C_COL0_P2 | FLAG_C_TAIL_P2 | FLAG_LR_OPENCV | FLAG_MEDIAN_REPLICATE
+N_TIMINGS = 6
+TIMING_NAMES = ("prefilter", "cost", "aggregation", "wta", "tail", "total")
+
+EXPORTS = (
+    "sv_default_params", "sv_create", "sv_destroy", "sv_set_params", "sv_get_params", "sv_set_stream",
+    "sv_compute_gray_host", "sv_compute_gray_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
+    "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
+    "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
+    "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
+    "sv_algorithmic_bytes", "sv_last_error", "sv_version")
+
+
+class Params(C.Structure):
+    """Mirror of struct sv_params (include/sv_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "min_disparity", "num_disparities", "block_size", "P1", "P2", "pre_filter_cap",
+        "uniqueness_ratio", "disp12_max_diff", "speckle_window_size", "speckle_range")] + [
+        ("path_mask", C.c_uint32), ("flags", C.c_uint32), ("wls_lambda", C.c_float), ("wls_sigma", C.c_float)]
+
+    def copy(self):
+        q = Params()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(Params))
+        return q
+
+
+class SvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsv_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libsv_hip.so and declare the ABI.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libsv_hip.so not built (%s): run `make -C stereo-vision_amd/csrc` or "
+                           "__graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    L.sv_version.restype = C.c_char_p
+    L.sv_last_error.restype = C.c_char_p
+    L.sv_last_error.argtypes = [vp]
+    L.sv_default_params.argtypes = [C.POINTER(Params), i32, i32]
+    L.sv_create.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(Params)]
+    L.sv_destroy.argtypes = [vp]
+    L.sv_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.sv_get_params.argtypes = [vp, C.POINTER(Params)]
+    L.sv_set_stream.argtypes = [vp, vp]
+    L.sv_compute_gray_host.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    L.sv_compute_gray_dev.argtypes = [vp, vp, vp, vp]
+    L.sv_gray_from_rgb_dev.argtypes = [vp, vp, vp]
+    L.sv_upload_maps_host.argtypes = [vp, vp, vp, vp, vp]
+    L.sv_remap_rgb_dev.argtypes = [vp, i32, vp, vp]
+    L.sv_compute_rgb_host.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz]
+    L.sv_get_rectified_host.argtypes = [vp, i32, vp, sz]
+    L.sv_disparity_vis_dev.argtypes = [vp, vp, vp, i32]
+    L.sv_disparity_vis_host.argtypes = [vp, vp, vp, i32]
+    L.sv_filter_speckles_dev.argtypes = [vp, vp, i32, i32]
+    L.sv_depth_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz]
+    L.sv_depth_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.sv_debug_read_volume_host.argtypes = [vp, i32, vp, sz]
+    L.sv_debug_read_plane_host.argtypes = [vp, i32, vp]
+    L.sv_enable_timing.argtypes = [vp, i32]
+    L.sv_get_timings.argtypes = [vp, C.POINTER(C.c_float), i32]
+    L.sv_algorithmic_bytes.restype = C.c_int64
+    L.sv_algorithmic_bytes.argtypes = [vp, i32]
+    _lib = L
+    return L
+
+
+def default_params(num_disparities, paths=8, **over):
+    p = Params()
+    rc = load().sv_default_params(C.byref(p), num_disparities, paths)
+    if rc:
+        raise SvError(rc, "sv_default_params")
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Matcher:
+    """One sv_ctx.  Mirrors the matcher part of StereoMatcherNew for one geometry."""
+
+    def __init__(self, width, height, params, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self.W, self.H = width, height
+        rc = self._L.sv_create(C.byref(self._h), device, width, height, C.byref(params))
+        if rc:
+            msg = self._L.sv_last_error(self._h).decode() if self._h else "sv_create failed"
+            if self._h:
+                self._L.sv_destroy(self._h)
+                self._h = C.c_void_p()
+            raise SvError(rc, msg)
+        self.params = params.copy()
+
+    def _chk(self, rc):
+        if rc:
+            raise SvError(rc, self._L.sv_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.sv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params):
+        self._chk(self._L.sv_set_params(self._h, C.byref(params)))
+        self.params = params.copy()
+
+    def set_stream(self, stream_handle):
+        self._chk(self._L.sv_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def enable_timing(self, on=True):
+        self._chk(self._L.sv_enable_timing(self._h, int(on)))
+
+    def timings(self):
+        ms = (C.c_float * N_TIMINGS)()
+        self._chk(self._L.sv_get_timings(self._h, ms, N_TIMINGS))
+        return dict(zip(TIMING_NAMES, list(ms)))
+
+    def algorithmic_bytes(self, which=4):
+        return int(self._L.sv_algorithmic_bytes(self._h, which))
+
+    # ---- host-buffer entry points (numpy) -------------------------------------------------
+    def compute_gray(self, left, right):
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        assert left.shape == (self.H, self.W) and right.shape == (self.H, self.W)
+        out = np.empty((self.H, self.W), np.int16)
+        self._chk(self._L.sv_compute_gray_host(self._h, _ptr(left), self.W, _ptr(right), self.W, _ptr(out), 2 * self.W))
+        return out
+
+    def upload_maps(self, mlx, mly, mrx, mry):
+        maps = [np.ascontiguousarray(m, np.float32) for m in (mlx, mly, mrx, mry)]
+        for m in maps:
+            assert m.shape == (self.H, self.W)
+        self._chk(self._L.sv_upload_maps_host(self._h, *[_ptr(m) for m in maps]))
+
+    def compute_rgb(self, left_rgb, right_rgb, rectify=True):
+        left_rgb = np.ascontiguousarray(left_rgb, np.uint8)
+        right_rgb = np.ascontiguousarray(right_rgb, np.uint8)
+        assert left_rgb.shape == (self.H, self.W, 3) and right_rgb.shape == (self.H, self.W, 3)
+        out = np.empty((self.H, self.W), np.int16)
+        self._chk(self._L.sv_compute_rgb_host(self._h, _ptr(left_rgb), 3 * self.W, _ptr(right_rgb), 3 * self.W,
+                                              int(rectify), _ptr(out), 2 * self.W))
+        return out
+
+    def rectified(self, which):
+        out = np.empty((self.H, self.W, 3), np.uint8)
+        self._chk(self._L.sv_get_rectified_host(self._h, which, _ptr(out), 3 * self.W))
+        return out
+
+    def disparity_vis(self, disp16, scale=3):
+        d = np.ascontiguousarray(disp16, np.int16)
+        out = np.empty((self.H, self.W), np.uint8)
+        self._chk(self._L.sv_disparity_vis_host(self._h, _ptr(d), _ptr(out), scale))
+        return out
+
+    def depth(self, disp16, mapper, Q, R):
+        d = np.ascontiguousarray(disp16, np.int16)
+        mapper = np.ascontiguousarray(mapper, np.float32)
+        Q = np.ascontiguousarray(Q, np.float64)
+        R = np.ascontiguousarray(R, np.float64)
+        assert mapper.shape == (self.H, self.W, 2) and Q.shape == (4, 4) and R.shape == (3, 3)
+        out = np.empty((self.H, self.W), np.float32)
+        self._chk(self._L.sv_depth_host(self._h, _ptr(d), 2 * self.W, _ptr(mapper), _ptr(Q), _ptr(R), _ptr(out),
+                                        4 * self.W))
+        return out
+
+    def debug_volume(self, which):
+        D = self.params.num_disparities
+        out = np.empty((self.H, self.W - D, D), np.int16)
+        self._chk(self._L.sv_debug_read_volume_host(self._h, which, _ptr(out), out.size))
+        return out
+
+    def debug_plane(self, which):
+        out = np.empty((self.H, self.W), np.int16)
+        self._chk(self._L.sv_debug_read_plane_host(self._h, which, _ptr(out)))
+        return out
+
+    # ---- device-pointer entry points (torch tensors own the memory) -----------------------
+    def compute_gray_dev(self, left_t, right_t, out_t):
+        """left_t/right_t: contiguous uint8 CUDA tensors [H][W]; out_t: int16 CUDA tensor [H][W]."""
+        self._chk(self._L.sv_compute_gray_dev(self._h, C.c_void_p(left_t.data_ptr()), C.c_void_p(right_t.data_ptr()),
+                                              C.c_void_p(out_t.data_ptr())))
+
+    def filter_speckles_dev(self, disp_t, max_size, max_diff):
+        self._chk(self._L.sv_filter_speckles_dev(self._h, C.c_void_p(disp_t.data_ptr()), max_size, max_diff))
+
+    def remap_rgb_dev(self, which, src_t, dst_t):
+        self._chk(self._L.sv_remap_rgb_dev(self._h, which, C.c_void_p(src_t.data_ptr()), C.c_void_p(dst_t.data_ptr())))
+
+    def gray_from_rgb_dev(self, rgb_t, gray_t):
+        self._chk(self._L.sv_gray_from_rgb_dev(self._h, C.c_void_p(rgb_t.data_ptr()), C.c_void_p(gray_t.data_ptr())))
