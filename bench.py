@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — disparity frames/s per GPU at 640x480, D=128, 8 paths (+ LR check), % of HBM roofline.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N = 1: plain process.  N > 1: launched by torch.distributed.run, one rank per GPU (RCCL is used
+  only for the timing barrier / max-over-ranks; stereo pairs are independent, so frames are
+  sharded across ranks with NO data-path collective -> "scaling": "weak").
+
+A "step" is one pass of the hot path (prefilter -> cost volume -> 8-path SGM -> WTA -> LR check ->
+median; sv_compute_gray_batch_dev) over one batch of synthetic stereo pairs that are already
+resident in HBM.  value = frames of all ranks / max-over-ranks wall time of exactly K steps.
+
+roofline: the dominant kernel is svk::k_agg (one SGM path over the whole batch per launch).  Its
+average launch duration is measured live with HIP events recorded by libsv_hip on the stream the
+kernels run on, over the K timed steps; achieved = algorithmic bytes per launch (3 * V * batch,
+V = (W-D)*H*D*2) / that duration.
+
+cpu_baseline: the CPU oracle (oracle/libsv_ref.so, a restatement = "port"; OpenCV is not
+installed) timed single-threaded on rank 0 on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "stereo-vision_amd"))
+
+CONFIGS = {
+    # name: (W, H, D, paths)
+    "c1": (320, 240, 64, 8),
+    "c2": (640, 480, 128, 8),   # the configuration BASELINE.json's metric is quoted on
+    "c4": (1920, 1080, 256, 8),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(W, H, D, paths, left, right, budget_s=12.0):
+    """Times the oracle on the host cores (1 thread): frames/s on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import svref  # oracle: checker / CPU comparator only, never on the product path
+    p = svref.default_params(D, paths)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        svref.sgbm(left[n % len(left)], right[n % len(right)], p)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 8:
+            break
+    out = {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of %dx%d D=%d %d-path SGBM, oracle/libsv_ref.so (restated SGBM; OpenCV not "
+                     "installed), single thread" % (n, W, H, D, paths)}
+    # the reference's own LIBELAS CPU matcher, if oracle/_ref was built in the dev container
+    try:
+        import ctypes
+        import numpy as np
+        so = os.path.join(ROOT, "oracle", "_ref", "libelas_ref.so")
+        if os.path.exists(so):
+            L = ctypes.CDLL(so)
+            L.elasref_process.restype = ctypes.c_int
+            d1 = np.empty((H, W), np.float32)
+            d2 = np.empty((H, W), np.float32)
+            args = [left[0].ctypes.data_as(ctypes.c_void_p), right[0].ctypes.data_as(ctypes.c_void_p),
+                    d1.ctypes.data_as(ctypes.c_void_p), d2.ctypes.data_as(ctypes.c_void_p), W, H, D - 1, 40]
+            L.elasref_process(*args)
+            m, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < 3.0:
+                L.elasref_process(*args)
+                m += 1
+            out["libelas"] = {"value": round(m / (time.perf_counter() - t1), 2), "unit": "frames/s",
+                              "kind": "reference", "cores": int(L.elasref_threads()),
+                              "sample": "%d frames, Elas::process ROBOTICS preset (elas_omp.cpp)" % m}
+    except Exception as e:  # comparator is optional
+        out["libelas_error"] = str(e)[:200]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step per GPU")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import svhip
+    from svhip import synth
+
+    W, H, D, paths = CONFIGS[args.config]
+    B = args.batch if args.config != "c4" else min(args.batch, 4)
+    params = svhip.default_params(D, paths)  # SAD 7, P1 8*49, P2 32*49, cap 63, uniq 15, LR check on
+    n_distinct = min(B, 8)
+    seed0 = 202 if world == 1 else 500 + 16 * rank
+    pairs = [synth.stereo_pair(seed0 + i, W, H, D) for i in range(n_distinct)]
+    lefts = [p[0] for p in pairs]
+    rights = [p[1] for p in pairs]
+    lt = torch.from_numpy(np.stack([lefts[i % n_distinct] for i in range(B)])).cuda()
+    rt = torch.from_numpy(np.stack([rights[i % n_distinct] for i in range(B)])).cuda()
+    out = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
+
+    m = svhip.Matcher(W, H, params, device=local_rank)
+    m.set_batch(B)
+    stream = torch.cuda.current_stream()
+    m.set_stream(stream.cuda_stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        m.compute_gray_batch_dev(B, lt, rt, out)
+    m.enable_timing(True)  # HIP events on the kernels' stream, read back after the timed region
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.compute_gray_batch_dev(B, lt, rt, out)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    stage_ms = m.timings()
+    m.enable_timing(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity: the timed output must be a plausible disparity map (not a skipped launch)
+    valid = float((out[:, :, D:] >= 0).float().mean().item())
+    if not valid > 0.5:
+        raise SystemExit("bench: output looks wrong (valid fraction %.3f)" % valid)
+
+    if rank == 0:
+        frames = world * B * args.steps
+        fps = frames / elapsed
+        V = (W - D) * H * D * 2
+        n_paths = bin(params.path_mask).count("1")
+        launch_s = stage_ms["aggregation"] * 1e-3 / n_paths          # mean duration of one k_agg launch
+        agg_bytes_per_launch = 3 * V * B                              # read C, read+write S, all frames of the batch
+        achieved = agg_bytes_per_launch / launch_s / 1e9
+        frame_bytes = m.algorithmic_bytes(4)
+        res = {
+            "metric": "disparity frames/sec per GPU at 640x480, D=128, 8 paths; % HBM roofline",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d D=%d %d-path SGM + LR check + median, bit-exact variant SGBM8_HH"
+                                   % (args.config, W, H, D, paths),
+                       "batch_per_gpu": B, "frames_per_step": world * B, "parallelism": "frame-sharded x%d" % world,
+                       "valid_fraction": round(valid, 4)},
+            "per_gpu_fps": round(fps / world, 2),
+            "frame_roofline_frac": round(frame_bytes * (fps / world) / (HBM_PEAK_GBS * 1e9), 4),
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": "svk::k_agg", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launch_us": round(launch_s * 1e6, 2), "bytes_per_launch": agg_bytes_per_launch},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(W, H, D, paths, lefts, rights)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

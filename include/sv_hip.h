@@ -141,6 +141,17 @@ int sv_compute_gray_host(sv_ctx* ctx, const uint8_t* left_host, size_t left_stri
 int sv_compute_gray_dev(sv_ctx* ctx, const uint8_t* left_dev, const uint8_t* right_dev,
                         int16_t* disp16_dev);
 
+/* Frame batching.  Stereo pairs are independent, so one launch can
+ * carry many of them: sv_set_batch sizes the internal volumes for up to
+ * max_frames pairs (288 GB of HBM hold hundreds of 640x480 D=128 frames) and
+ * sv_compute_gray_batch_dev runs n_frames dense-packed pairs ([n][H][W] u8 in,
+ * [n][H][W] int16 out) through the same kernels with the frame index as a grid
+ * dimension.  No counterpart in the reference (one frame, static buffers,
+ * bova_sgm.cu:7-30); the single-frame entry points are the batch of one.      */
+int sv_set_batch(sv_ctx* ctx, int max_frames);
+int sv_compute_gray_batch_dev(sv_ctx* ctx, int n_frames, const uint8_t* left_dev, const uint8_t* right_dev,
+                              int16_t* disp16_dev);
+
 /* Replaces the two cv::cvtColor(.., CV_BGR2GRAY) calls of matchSGBMCUDA
  * (StereoMatcher.cpp:429-430) applied to RGB-ordered bytes; 3 bytes/pixel in,
  * 1 byte/pixel out, both on the device.                                       */
@@ -193,8 +204,11 @@ int sv_debug_read_volume_host(sv_ctx* ctx, int which, int16_t* vol_host, size_t 
  * 3 = disp after LR check (before median).  width*height int16.               */
 int sv_debug_read_plane_host(sv_ctx* ctx, int which, int16_t* plane_host);
 
-/* Per-stage GPU time of the last sv_compute_* call in milliseconds, measured
- * with HIP events on the context stream (enable with sv_enable_timing).
+/* Per-stage GPU time in milliseconds, measured with HIP events recorded on the
+ * context stream around each stage of every sv_compute_* call made since
+ * sv_enable_timing(ctx, 1); sv_get_timings synchronises the stream and returns
+ * the MEAN over those calls (the most recent 64 at most).  For a batched call
+ * the figures are per launch, i.e. for all frames of the batch.
  * Order: 0 prefilter, 1 cost, 2 aggregation, 3 wta, 4 lr+median(+speckle),
  * 5 total.  Replaces the commented PROF_S/PROF_E macros (DispModule.cpp:24-69). */
 #define SV_N_TIMINGS 6

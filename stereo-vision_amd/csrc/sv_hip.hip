@@ -27,6 +27,7 @@ struct Buf {
 struct sv_ctx {
     int device = 0;
     int W = 0, H = 0;
+    int batch = 1;  // frames per launch the volume buffers are sized for
     sv_params prm{};
     hipStream_t stream = nullptr;
     char err[512] = {0};
@@ -48,11 +49,13 @@ struct sv_ctx {
     Buf lab, cnt;            // int [H][W] speckle union-find
     bool have_maps = false;
 
+    // stage timing: a ring of event sets, one set per compute call, read back (and averaged)
+    // only in sv_get_timings so that recording never synchronises the stream
+    static constexpr int EV_RING = 64, EV_PER = SV_N_TIMINGS;  // 6 marks per call
     bool timing = false;
-    hipEvent_t ev[SV_N_TIMINGS + 1] = {};
+    hipEvent_t ev[EV_RING][EV_PER] = {};
     bool ev_ok = false;
-    float ms[SV_N_TIMINGS] = {0};
-    bool ms_valid = false;
+    long ev_calls = 0;  // compute calls recorded since sv_enable_timing
 };
 
 namespace {
@@ -113,8 +116,8 @@ void release(Buf& b) {
 }
 
 int alloc_core(sv_ctx* c) {
-    const size_t npx = (size_t)c->W * c->H;
-    const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities;
+    const size_t npx = (size_t)c->W * c->H * c->batch;
+    const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities * c->batch;
     int rc;
     if ((rc = ensure(c, c->stat_l, npx * 8))) return rc;
     if ((rc = ensure(c, c->stat_r, npx * 8))) return rc;
@@ -142,14 +145,14 @@ struct DevGuard {
 };
 
 template <int N>
-void launch_agg_n(sv_ctx* c, int dir, bool first) {
+void launch_agg_n(sv_ctx* c, int dir, bool first, int nb) {
     static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
     const int dx = DX[dir], dy = DY[dir];
     const bool vert = dy != 0;
     const int nchains = vert ? W1 : H;
-    const dim3 grid((nchains + 3) / 4), block(64);
+    const dim3 grid((nchains + 3) / 4, nb), block(64);
     const uint32_t P1P1 = (uint32_t)c->prm.P1 * 0x10001u, P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
     const uint32_t* Cv = (const uint32_t*)c->C.p;
     uint32_t* Sv = (uint32_t*)c->S.p;
@@ -163,45 +166,45 @@ void launch_agg_n(sv_ctx* c, int dir, bool first) {
     }
 }
 
-void launch_agg(sv_ctx* c, int dir, bool first) {
+void launch_agg(sv_ctx* c, int dir, bool first, int nb) {
     switch (c->prm.num_disparities / 32) {
-        case 1: launch_agg_n<1>(c, dir, first); break;
-        case 2: launch_agg_n<2>(c, dir, first); break;
-        case 3: launch_agg_n<3>(c, dir, first); break;
-        case 4: launch_agg_n<4>(c, dir, first); break;
-        case 5: launch_agg_n<5>(c, dir, first); break;
-        case 6: launch_agg_n<6>(c, dir, first); break;
-        case 7: launch_agg_n<7>(c, dir, first); break;
-        default: launch_agg_n<8>(c, dir, first); break;
+        case 1: launch_agg_n<1>(c, dir, first, nb); break;
+        case 2: launch_agg_n<2>(c, dir, first, nb); break;
+        case 3: launch_agg_n<3>(c, dir, first, nb); break;
+        case 4: launch_agg_n<4>(c, dir, first, nb); break;
+        case 5: launch_agg_n<5>(c, dir, first, nb); break;
+        case 6: launch_agg_n<6>(c, dir, first, nb); break;
+        case 7: launch_agg_n<7>(c, dir, first, nb); break;
+        default: launch_agg_n<8>(c, dir, first, nb); break;
     }
 }
 
 template <int N>
-void launch_wta_n(sv_ctx* c) {
+void launch_wta_n(sv_ctx* c, int nb) {
     const size_t npx = (size_t)c->W * c->H;
-    const dim3 grid((unsigned)((npx * 16 + 255) / 256)), block(256);
+    const dim3 grid((unsigned)((npx * 16 + 255) / 256), nb), block(256);
     hipLaunchKernelGGL((svk::k_wta<N>), grid, block, 0, c->stream, (const uint32_t*)c->S.p, (int16_t*)c->disp.p,
                        (int16_t*)c->raw.p, (int16_t*)c->mins.p, c->W, c->H, c->prm.uniqueness_ratio);
 }
-void launch_wta(sv_ctx* c) {
+void launch_wta(sv_ctx* c, int nb) {
     switch (c->prm.num_disparities / 32) {
-        case 1: launch_wta_n<1>(c); break;
-        case 2: launch_wta_n<2>(c); break;
-        case 3: launch_wta_n<3>(c); break;
-        case 4: launch_wta_n<4>(c); break;
-        case 5: launch_wta_n<5>(c); break;
-        case 6: launch_wta_n<6>(c); break;
-        case 7: launch_wta_n<7>(c); break;
-        default: launch_wta_n<8>(c); break;
+        case 1: launch_wta_n<1>(c, nb); break;
+        case 2: launch_wta_n<2>(c, nb); break;
+        case 3: launch_wta_n<3>(c, nb); break;
+        case 4: launch_wta_n<4>(c, nb); break;
+        case 5: launch_wta_n<5>(c, nb); break;
+        case 6: launch_wta_n<6>(c, nb); break;
+        case 7: launch_wta_n<7>(c, nb); break;
+        default: launch_wta_n<8>(c, nb); break;
     }
 }
 
-int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff) {
-    const int n = c->W * c->H;
+int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff, int nb) {
+    const int n = c->W * c->H * nb;
     int rc;
     if ((rc = ensure(c, c->lab, (size_t)n * 4))) return rc;
     if ((rc = ensure(c, c->cnt, (size_t)n * 4))) return rc;
-    const dim3 b(256), g1((n + 255) / 256), g2((c->W + 255) / 256, c->H);
+    const dim3 b(256), g1((n + 255) / 256), g2((c->W + 255) / 256, c->H, nb);
     int* lab = (int*)c->lab.p;
     int* cnt = (int*)c->cnt.p;
     hipLaunchKernelGGL(svk::k_speckle_init, g1, b, 0, c->stream, img, lab, cnt, n);
@@ -213,25 +216,26 @@ int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff) {
 }
 
 // The matcher proper: device gray pair -> device disparity16.
-int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp16) {
+int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp16, int nb = 1) {
     const sv_params& p = c->prm;
     const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
     const bool tm = c->timing && c->ev_ok;
     int e = 0;
-    auto mark = [&]() { if (tm) (void)hipEventRecord(c->ev[e++], c->stream); };
+    hipEvent_t* evs = c->ev[c->ev_calls % sv_ctx::EV_RING];
+    auto mark = [&]() { if (tm) (void)hipEventRecord(evs[e++], c->stream); };
     mark();
     // 1. prefilter + BT statistics
-    hipLaunchKernelGGL(svk::k_stats, dim3((W + 255) / 256, H, 2), dim3(256), 0, c->stream, left, right, (uint2*)c->stat_l.p,
+    hipLaunchKernelGGL(svk::k_stats, dim3((W + 255) / 256, H, 2 * nb), dim3(256), 0, c->stream, left, right, (uint2*)c->stat_l.p,
                        (uint2*)c->stat_r.p, W, H, p.pre_filter_cap);
     mark();
     // 2. matching cost volume C
     {
         const int ncol = svk::COST_TX + 2 * r;
         const size_t sm = (size_t)(svk::COST_TX + 10 + 256) * 8 + (size_t)(svk::COST_TX + 10) * 8 + (size_t)ncol * (D / 2) * 4;
-        hipLaunchKernelGGL(svk::k_pix_hsum, dim3((W1 + svk::COST_TX - 1) / svk::COST_TX, H), dim3(256), sm, c->stream,
+        hipLaunchKernelGGL(svk::k_pix_hsum, dim3((W1 + svk::COST_TX - 1) / svk::COST_TX, H, nb), dim3(256), sm, c->stream,
                            (const uint2*)c->stat_l.p, (const uint2*)c->stat_r.p, (uint32_t*)c->hs.p, W, H, D, r);
         const size_t rowN = (size_t)W1 * (D / 2);
-        hipLaunchKernelGGL(svk::k_vsum, dim3((unsigned)((rowN + 255) / 256), (H + svk::VSUM_BAND - 1) / svk::VSUM_BAND), dim3(256),
+        hipLaunchKernelGGL(svk::k_vsum, dim3((unsigned)((rowN + 255) / 256), (H + svk::VSUM_BAND - 1) / svk::VSUM_BAND, nb), dim3(256),
                            0, c->stream, (const uint32_t*)c->hs.p, (uint32_t*)c->C.p, W1, H, D, r, (uint32_t)p.P2 * 0x10001u,
                            (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0);
     }
@@ -241,42 +245,39 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         bool first = true;
         for (int dir = 0; dir < 8; dir++)
             if (p.path_mask & (1u << dir)) {
-                launch_agg(c, dir, first);
+                launch_agg(c, dir, first, nb);
                 first = false;
             }
     }
     mark();
     // 4. WTA
-    launch_wta(c);
+    launch_wta(c, nb);
     mark();
     // 5. LR check, median, speckle
     const int16_t* cur = (const int16_t*)c->disp.p;
     if (!(p.flags & SV_FLAG_NO_LRCHECK)) {
         int thr = p.disp12_max_diff;
         if (p.flags & SV_FLAG_LR_OPENCV) thr = thr > 0 ? thr : 1;
-        hipLaunchKernelGGL(svk::k_lrcheck, dim3(H), dim3(256), (size_t)W * 4, c->stream, cur, (const int16_t*)c->raw.p,
+        hipLaunchKernelGGL(svk::k_lrcheck, dim3(H, nb), dim3(256), (size_t)W * 4, c->stream, cur, (const int16_t*)c->raw.p,
                            (const int16_t*)c->mins.p, (int16_t*)c->disp_lr.p, W, D, thr);
         cur = (const int16_t*)c->disp_lr.p;
     } else {
-        HIPCHK(c, hipMemcpyAsync(c->disp_lr.p, cur, (size_t)W * H * 2, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->disp_lr.p, cur, (size_t)W * H * 2 * nb, hipMemcpyDeviceToDevice, c->stream));
         cur = (const int16_t*)c->disp_lr.p;
     }
     if (!(p.flags & SV_FLAG_NO_MEDIAN)) {
-        hipLaunchKernelGGL(svk::k_median3, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, cur, disp16, W, H,
+        hipLaunchKernelGGL(svk::k_median3, dim3((W + 255) / 256, H, nb), dim3(256), 0, c->stream, cur, disp16, W, H,
                            (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
     } else {
-        HIPCHK(c, hipMemcpyAsync(disp16, cur, (size_t)W * H * 2, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(disp16, cur, (size_t)W * H * 2 * nb, hipMemcpyDeviceToDevice, c->stream));
     }
     if (p.speckle_window_size > 0) {
-        int rc = speckle_dev(c, disp16, p.speckle_window_size, 16 * p.speckle_range);
+        int rc = speckle_dev(c, disp16, p.speckle_window_size, 16 * p.speckle_range, nb);
         if (rc) return rc;
     }
     mark();
     HIPCHK(c, hipGetLastError());
-    if (tm) {
-        (void)hipEventRecord(c->ev[SV_N_TIMINGS], c->stream);
-        c->ms_valid = true;
-    }
+    if (tm) c->ev_calls++;
     return SV_OK;
 }
 
@@ -329,7 +330,8 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, SV_ERR_NO_DEVICE, "device %d is %s; libsv_hip is built for gfx950 only", device, prop.gcnArchName);
-    for (int i = 0; i <= SV_N_TIMINGS; i++) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    for (int r = 0; r < sv_ctx::EV_RING; r++)
+        for (int i = 0; i < sv_ctx::EV_PER; i++) HIPCHK(c, hipEventCreate(&c->ev[r][i]));
     c->ev_ok = true;
     return alloc_core(c);
 }
@@ -346,7 +348,9 @@ int sv_destroy(sv_ctx* c) {
                           &c->lab, &c->cnt};
             for (Buf* b : all) release(*b);
             if (c->ev_ok)
-                for (int i = 0; i <= SV_N_TIMINGS; i++) (void)hipEventDestroy(c->ev[i]);
+                for (int r = 0; r < sv_ctx::EV_RING; r++)
+                    for (int i = 0; i < sv_ctx::EV_PER; i++)
+                        if (c->ev[r][i]) (void)hipEventDestroy(c->ev[r][i]);
         }
     }
     delete c;
@@ -383,6 +387,27 @@ int sv_compute_gray_dev(sv_ctx* c, const uint8_t* left_dev, const uint8_t* right
     DevGuard g(c->device);
     if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     return run_sgm(c, left_dev, right_dev, disp16_dev);
+}
+
+int sv_set_batch(sv_ctx* c, int max_frames) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (max_frames < 1 || max_frames > 1024) return fail(c, SV_ERR_INVALID_ARG, "batch must be in [1,1024] (got %d)", max_frames);
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    if (max_frames != c->batch) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->batch = max_frames;
+    return alloc_core(c);
+}
+
+int sv_compute_gray_batch_dev(sv_ctx* c, int n_frames, const uint8_t* left_dev, const uint8_t* right_dev,
+                              int16_t* disp16_dev) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!left_dev || !right_dev || !disp16_dev) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer");
+    if (n_frames < 1 || n_frames > c->batch)
+        return fail(c, SV_ERR_INVALID_ARG, "n_frames %d outside [1, batch=%d] (sv_set_batch)", n_frames, c->batch);
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    return run_sgm(c, left_dev, right_dev, disp16_dev, n_frames);
 }
 
 int sv_compute_gray_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int16_t* disp16, size_t ds) {
@@ -512,7 +537,7 @@ int sv_filter_speckles_dev(sv_ctx* c, int16_t* d16, int max_size, int max_diff) 
     if (!c) return SV_ERR_INVALID_ARG;
     if (!d16 || max_size < 0 || max_diff < 0) return fail(c, SV_ERR_INVALID_ARG, "bad speckle argument");
     DevGuard g(c->device);
-    return speckle_dev(c, d16, max_size, max_diff);
+    return speckle_dev(c, d16, max_size, max_diff, 1);
 }
 
 int sv_depth_dev(sv_ctx* c, const int16_t* d16, const float* mapper, const double* Q, const double* R, float* depth) {
@@ -571,19 +596,31 @@ int sv_debug_read_plane_host(sv_ctx* c, int which, int16_t* plane) {
 int sv_enable_timing(sv_ctx* c, int enable) {
     if (!c) return SV_ERR_INVALID_ARG;
     c->timing = enable != 0;
-    c->ms_valid = false;
+    c->ev_calls = 0;
     return SV_OK;
 }
 
 int sv_get_timings(sv_ctx* c, float* ms, int n) {
     if (!c) return SV_ERR_INVALID_ARG;
     if (!ms || n < SV_N_TIMINGS) return fail(c, SV_ERR_INVALID_ARG, "need room for %d timings", SV_N_TIMINGS);
-    if (!c->ms_valid) return fail(c, SV_ERR_INVALID_ARG, "no timed frame yet (sv_enable_timing, then compute)");
+    if (c->ev_calls <= 0) return fail(c, SV_ERR_INVALID_ARG, "no timed call yet (sv_enable_timing, then compute)");
     DevGuard g(c->device);
-    HIPCHK(c, hipEventSynchronize(c->ev[SV_N_TIMINGS]));
-    // events: 0 start, 1 after stats, 2 after cost, 3 after agg, 4 after wta, 5 after tail
-    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
-    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // marks of one call: 0 start, 1 after stats, 2 after cost, 3 after agg, 4 after wta, 5 after tail.
+    // Mean over the calls still in the ring (at most EV_RING most recent ones).
+    const long nset = c->ev_calls < sv_ctx::EV_RING ? c->ev_calls : sv_ctx::EV_RING;
+    double acc[SV_N_TIMINGS] = {0};
+    for (long k = 0; k < nset; k++) {
+        hipEvent_t* evs = c->ev[(c->ev_calls - 1 - k) % sv_ctx::EV_RING];
+        float t;
+        for (int i = 0; i < 5; i++) {
+            HIPCHK(c, hipEventElapsedTime(&t, evs[i], evs[i + 1]));
+            acc[i] += t;
+        }
+        HIPCHK(c, hipEventElapsedTime(&t, evs[0], evs[5]));
+        acc[5] += t;
+    }
+    for (int i = 0; i < SV_N_TIMINGS; i++) ms[i] = (float)(acc[i] / (double)nset);
     return SV_OK;
 }
 

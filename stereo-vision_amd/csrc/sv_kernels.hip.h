@@ -122,8 +122,9 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t* __restrict__ left,
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
-    const uint8_t* img = blockIdx.z ? right : left;
-    uint2* out = blockIdx.z ? stat_r : stat_l;
+    const size_t fo = (size_t)(blockIdx.z >> 1) * W * H;  // frame offset (batched launch)
+    const uint8_t* img = ((blockIdx.z & 1) ? right : left) + fo;
+    uint2* out = ((blockIdx.z & 1) ? stat_r : stat_l) + fo;
     int g = grad_at(img, W, H, x, y, cap), r = raw_at(img, W, x, y, cap);
     int gl = x > 0 ? (g + grad_at(img, W, H, x - 1, y, cap)) / 2 : g;
     int gr = x < W - 1 ? (g + grad_at(img, W, H, x + 1, y, cap)) / 2 : g;
@@ -167,8 +168,10 @@ __global__ __launch_bounds__(256) void k_pix_hsum(const uint2* __restrict__ stat
     uint2* Rs = reinterpret_cast<uint2*>(smem);
     uint2* Ls = Rs + (COST_TX + 2 * 5 + 256);
     uint32_t* pix = reinterpret_cast<uint32_t*>(Ls + (COST_TX + 2 * 5));  // [ncol][D2]
-    const uint2* lrow = stat_l + (size_t)y * W;
-    const uint2* rrow = stat_r + (size_t)y * W;
+    const size_t fpx = (size_t)blockIdx.z * W * H;
+    const uint2* lrow = stat_l + fpx + (size_t)y * W;
+    const uint2* rrow = stat_r + fpx + (size_t)y * W;
+    hs += (size_t)blockIdx.z * H * W1 * D2;
     for (int i = threadIdx.x; i < nr; i += blockDim.x) Rs[i] = rrow[rbase + i];
     for (int j = threadIdx.x; j < ncol; j += blockDim.x) {
         int xl = min(max(xl0 - radius + j, 0), W1 - 1);
@@ -213,6 +216,8 @@ __global__ __launch_bounds__(256) void k_vsum(const uint32_t* __restrict__ hs, u
     const int y0 = blockIdx.y * VSUM_BAND, y1 = min(y0 + VSUM_BAND, H);
     const int ylast = H - 1 - radius;
     const bool col0 = e < (size_t)D2;
+    hs += (size_t)blockIdx.z * H * rowN;
+    C += (size_t)blockIdx.z * H * rowN;
     const int ys = min(y0, ylast);
     uint32_t acc = 0;
     for (int k = -radius; k <= radius; k++) acc += hs[(size_t)max(ys + k, 0) * rowN + e];
@@ -258,87 +263,121 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
                                              int dy, uint32_t P1P1, uint32_t P2P2) {
     const int q = threadIdx.x & 15;
     const int nchains = VERT ? W1 : H, nsteps = VERT ? H : W1;
-    int chain = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
-    const bool valid = chain < nchains;
-    chain = min(chain, nchains - 1);
+    // Chains past the end repeat the last chain: same loads, same arithmetic, same stores from
+    // lanes of the SAME wave (lock-step), so the duplicates are harmless and the loop stays
+    // branch-free (a predicated store would split the body into blocks and make hipcc drain
+    // vmcnt(0) at every block edge, which serialises the prefetch).
+    const int chain = min((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), nchains - 1);
     const size_t pxN = (size_t)16 * N;  // u32 per pixel
     const uint32_t laneoff = (uint32_t)q * N;
+    C += (size_t)blockIdx.y * H * W1 * pxN;  // frame of a batched launch
+    S += (size_t)blockIdx.y * H * W1 * pxN;
 
     // load cursor (runs one batch ahead of the compute)
     int lx, ly;
     if (VERT) { lx = chain; ly = dy > 0 ? 0 : H - 1; }
     else      { ly = chain; lx = dx > 0 ? 0 : W1 - 1; }
 
-    auto issue = [&](int i0, AggBatch<N, U>& b) {
-        b.rst = 0;
+    auto issue = [&](AggBatch<N, U>& b) {
+        uint32_t rs = 0;
 #pragma unroll
         for (int j = 0; j < U; j++) {
-            if (i0 + j < nsteps) {
-                b.off[j] = ((size_t)ly * W1 + lx) * pxN + laneoff;
-                load_regs<N>(C + b.off[j], b.c[j]);
-                if (!FIRST) load_regs<N>(S + b.off[j], b.s[j]);
-                if (VERT) {
-                    ly += dy;
-                    lx += dx;
-                    if (lx >= W1) { lx = 0; b.rst |= 2u << j; }
-                    if (lx < 0) { lx = W1 - 1; b.rst |= 2u << j; }
-                } else {
-                    lx += dx;
-                }
+            // clamped: a prefetch that runs past the last step reads a valid (unused) pixel
+            const int cy = min(max(ly, 0), H - 1), cx = min(max(lx, 0), W1 - 1);
+            b.off[j] = ((size_t)cy * W1 + cx) * pxN + laneoff;
+            load_regs<N>(C + b.off[j], b.c[j]);
+            if (!FIRST) load_regs<N>(S + b.off[j], b.s[j]);
+            if (VERT) {
+                ly += dy;
+                lx += dx;
+                const bool wrap = (lx >= W1) | (lx < 0);
+                lx = lx >= W1 ? 0 : (lx < 0 ? W1 - 1 : lx);
+                rs |= wrap ? (2u << j) : 0u;
+            } else {
+                lx += dx;
             }
         }
+        b.rst = rs;
     };
 
     uint32_t r[N];
 #pragma unroll
     for (int k = 0; k < N; k++) r[k] = 0;
     uint32_t dd = P2P2;
-    uint32_t carry = 0;  // fresh-start flag for step 0 of the next batch
 
-    auto compute = [&](int i0, AggBatch<N, U>& b) {
+    auto step = [&](const uint32_t (&c)[N], const uint32_t (&s)[N], size_t off, bool fresh) {
+        if (VERT) {
+            const uint32_t keep = fresh ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < N; k++) r[k] &= keep;
+            dd = fresh ? P2P2 : dd;
+        }
+        const uint32_t prevHi = dpp<DPP_ROW_SHR1>(0x7FFF7FFFu, r[N - 1]);
+        const uint32_t nextLo = dpp<DPP_ROW_SHL1>(0x7FFF7FFFu, r[0]);
+        uint32_t m[N + 1];
+        m[0] = __builtin_amdgcn_alignbit(r[0], prevHi, 16);
+#pragma unroll
+        for (int k = 1; k < N; k++) m[k] = __builtin_amdgcn_alignbit(r[k], r[k - 1], 16);
+        m[N] = __builtin_amdgcn_alignbit(nextLo, r[N - 1], 16);
+        uint32_t mn = 0xFFFFFFFFu;
+        uint32_t snew[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            uint32_t t = pk_add(pk_min(m[k], m[k + 1]), P1P1);
+            t = pk_min(pk_min(t, r[k]), dd);
+            uint32_t L = pk_sub(pk_add(c[k], t), dd);
+            r[k] = L;
+            mn = pk_min(mn, L);
+            snew[k] = FIRST ? L : pk_min(pk_add(s[k], L), 0x7FFF7FFFu);
+        }
+        mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // both halves = lane minimum
+        mn = row16_min_u32(mn);
+        dd = mn + P2P2;  // halves cannot carry: min + P2 < 65536
+        store_regs<N>(S + off, snew);
+    };
+
+    uint32_t carry = 0;  // fresh-start flag for step 0 of the next batch
+    auto compute = [&](AggBatch<N, U>& b) {
         const uint32_t flags = b.rst | carry;
 #pragma unroll
-        for (int j = 0; j < U; j++) {
-            if (i0 + j < nsteps) {
-                if (VERT && ((flags >> j) & 1u)) {
-#pragma unroll
-                    for (int k = 0; k < N; k++) r[k] = 0;
-                    dd = P2P2;
-                }
-                const uint32_t prevHi = dpp<DPP_ROW_SHR1>(0x7FFF7FFFu, r[N - 1]);
-                const uint32_t nextLo = dpp<DPP_ROW_SHL1>(0x7FFF7FFFu, r[0]);
-                uint32_t m[N + 1];
-                m[0] = __builtin_amdgcn_alignbit(r[0], prevHi, 16);
-#pragma unroll
-                for (int k = 1; k < N; k++) m[k] = __builtin_amdgcn_alignbit(r[k], r[k - 1], 16);
-                m[N] = __builtin_amdgcn_alignbit(nextLo, r[N - 1], 16);
-                uint32_t mn = 0xFFFFFFFFu;
-                uint32_t snew[N];
-#pragma unroll
-                for (int k = 0; k < N; k++) {
-                    uint32_t t = pk_add(pk_min(m[k], m[k + 1]), P1P1);
-                    t = pk_min(pk_min(t, r[k]), dd);
-                    uint32_t L = pk_sub(pk_add(b.c[j][k], t), dd);
-                    r[k] = L;
-                    mn = pk_min(mn, L);
-                    snew[k] = FIRST ? L : pk_min(pk_add(b.s[j][k], L), 0x7FFF7FFFu);
-                }
-                mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // both halves = lane minimum
-                mn = row16_min_u32(mn);
-                dd = mn + P2P2;  // halves cannot carry: min + P2 < 65536
-                if (valid) store_regs<N>(S + b.off[j], snew);
-            }
-        }
+        for (int j = 0; j < U; j++) step(b.c[j], b.s[j], b.off[j], (flags >> j) & 1u);
         carry = (b.rst >> U) & 1u;
     };
 
+    // main loop: full double batches only, no branch inside
+    const int nfull = nsteps - nsteps % (2 * U);
     AggBatch<N, U> A, B;
-    issue(0, A);
-    for (int i0 = 0; i0 < nsteps; i0 += 2 * U) {
-        issue(i0 + U, B);
-        compute(i0, A);
-        issue(i0 + 2 * U, A);
-        compute(i0 + U, B);
+    if (nfull > 0) {
+        issue(A);
+        for (int i0 = 0; i0 < nfull; i0 += 2 * U) {
+            issue(B);
+            compute(A);
+            issue(A);  // the last one is an unused, clamped prefetch
+            compute(B);
+        }
+    }
+    // tail (< 2U steps): closed-form position, no pipelining
+    for (int i = nfull; i < nsteps; i++) {
+        int x, y;
+        bool fresh = false;
+        if (VERT) {
+            y = dy > 0 ? i : H - 1 - i;
+            x = (chain + dx * i) % W1;
+            x = x < 0 ? x + W1 : x;
+            fresh = i > 0 && ((dx > 0 && x == 0) || (dx < 0 && x == W1 - 1));
+        } else {
+            y = chain;
+            x = dx > 0 ? i : W1 - 1 - i;
+        }
+        const size_t off = ((size_t)y * W1 + x) * pxN + laneoff;
+        uint32_t c[N], s[N];
+        load_regs<N>(C + off, c);
+        if (!FIRST) load_regs<N>(S + off, s);
+        else {
+#pragma unroll
+            for (int k = 0; k < N; k++) s[k] = 0;
+        }
+        step(c, s, off, fresh);
     }
 }
 
@@ -359,6 +398,8 @@ __global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, int
     const size_t p = inimg ? pid : npx - 1;
     const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
     const int xl = max(x - D, 0);
+    S += (size_t)blockIdx.y * H * W1 * 16 * N;
+    disp += (size_t)blockIdx.y * npx; raw += (size_t)blockIdx.y * npx; mins += (size_t)blockIdx.y * npx;
     uint32_t s[N];
     load_regs<N>(S + ((size_t)y * W1 + xl) * 16 * N + q * N, s);
     const int dbase = q * 2 * N;
@@ -415,7 +456,7 @@ __global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ dis
                                                   const int16_t* __restrict__ mins, int16_t* __restrict__ out, int W, int D,
                                                   int thresh) {
     extern __shared__ uint32_t keys[];
-    const int y = blockIdx.x;
+    const int y = blockIdx.x + blockIdx.y * gridDim.x;  // gridDim.x = H, blockIdx.y = frame
     const int16_t* dp = disp + (size_t)y * W;
     const int16_t* rw = raw + (size_t)y * W;
     const int16_t* mn = mins + (size_t)y * W;
@@ -455,6 +496,8 @@ __global__ __launch_bounds__(256) void k_median3(const int16_t* __restrict__ in,
                                                   int replicate) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
+    in += (size_t)blockIdx.z * W * H;
+    out += (size_t)blockIdx.z * W * H;
     const bool border = (x < 1 || y < 1 || x >= W - 1 || y >= H - 1);
     if (border && !replicate) { out[(size_t)y * W + x] = in[(size_t)y * W + x]; return; }
     int v[9];
@@ -507,7 +550,7 @@ __global__ __launch_bounds__(256) void k_speckle_merge(const int16_t* __restrict
                                                         int new_val, int max_diff) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
-    int i = y * W + x, v = img[i];
+    int i = (blockIdx.z * H + y) * W + x, v = img[i];
     if (v == new_val) return;
     if (x + 1 < W) { int u = img[i + 1]; if (u != new_val && abs(u - v) <= max_diff) uf_union(lab, i, i + 1); }
     if (y + 1 < H) { int u = img[i + W]; if (u != new_val && abs(u - v) <= max_diff) uf_union(lab, i, i + W); }

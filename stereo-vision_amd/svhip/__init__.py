@@ -26,7 +26,7 @@ TIMING_NAMES = ("prefilter", "cost", "aggregation", "wta", "tail", "total")
 
 EXPORTS = (
     "sv_default_params", "sv_create", "sv_destroy", "sv_set_params", "sv_get_params", "sv_set_stream",
-    "sv_compute_gray_host", "sv_compute_gray_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
+    "sv_compute_gray_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
     "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
@@ -76,6 +76,8 @@ def load():
     L.sv_set_stream.argtypes = [vp, vp]
     L.sv_compute_gray_host.argtypes = [vp, vp, sz, vp, sz, vp, sz]
     L.sv_compute_gray_dev.argtypes = [vp, vp, vp, vp]
+    L.sv_set_batch.argtypes = [vp, i32]
+    L.sv_compute_gray_batch_dev.argtypes = [vp, i32, vp, vp, vp]
     L.sv_gray_from_rgb_dev.argtypes = [vp, vp, vp]
     L.sv_upload_maps_host.argtypes = [vp, vp, vp, vp, vp]
     L.sv_remap_rgb_dev.argtypes = [vp, i32, vp, vp]
@@ -221,6 +223,14 @@ class Matcher:
         """left_t/right_t: contiguous uint8 CUDA tensors [H][W]; out_t: int16 CUDA tensor [H][W]."""
         self._chk(self._L.sv_compute_gray_dev(self._h, C.c_void_p(left_t.data_ptr()), C.c_void_p(right_t.data_ptr()),
                                               C.c_void_p(out_t.data_ptr())))
+
+    def set_batch(self, n):
+        self._chk(self._L.sv_set_batch(self._h, n))
+
+    def compute_gray_batch_dev(self, n, left_t, right_t, out_t):
+        """left_t/right_t: uint8 CUDA tensors [n][H][W]; out_t: int16 CUDA tensor [n][H][W]."""
+        self._chk(self._L.sv_compute_gray_batch_dev(self._h, n, C.c_void_p(left_t.data_ptr()),
+                                                    C.c_void_p(right_t.data_ptr()), C.c_void_p(out_t.data_ptr())))
 
     def filter_speckles_dev(self, disp_t, max_size, max_diff):
         self._chk(self._L.sv_filter_speckles_dev(self._h, C.c_void_p(disp_t.data_ptr()), max_size, max_diff))

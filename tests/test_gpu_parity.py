@@ -57,3 +57,29 @@ def test_single_paths(gpu, mask):
     assert np.array_equal(m.debug_volume(1), st["S"])
     assert np.array_equal(got, ref)
     m.close()
+
+
+def test_batched_launch_matches_oracle(gpu):
+    """Frame-batched entry point: every frame of the batch equals the oracle's frame."""
+    import torch
+    W, H, D, nb = 160, 64, 64, 5
+    ph, po = _params(D, 8, speckle_window_size=30, speckle_range=2)
+    pairs = [synth.stereo_pair(700 + i, W, H, D) for i in range(nb)]
+    lt = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    rt = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    out = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+    m = svhip.Matcher(W, H, ph)
+    m.set_batch(nb)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in range(nb):
+        assert np.array_equal(got[i], svref.sgbm(pairs[i][0], pairs[i][1], po)), "frame %d differs" % i
+    # a smaller batch on the same context
+    m.compute_gray_batch_dev(2, lt[3:], rt[3:], out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out[:2].cpu().numpy(), got[3:5])
+    with pytest.raises(svhip.SvError):
+        m.compute_gray_batch_dev(nb + 1, lt, rt, out)
+    m.close()
