@@ -63,6 +63,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libsv_hip.so not built (%s): run `make -C stereo-vision_amd/csrc` or "
                            "__graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64; importing torch first makes
+    # libsv_hip's dependency resolve to that already-loaded runtime (same soname) so that device
+    # pointers, streams and devices are shared.  Loading the system runtime first and torch's
+    # second leaves the later one without devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     L.sv_version.restype = C.c_char_p
