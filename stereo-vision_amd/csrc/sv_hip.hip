@@ -36,7 +36,8 @@ struct sv_ctx {
     Buf img_l, img_r;        // u8 [H][W] staging for the host entry points
     Buf stat_l, stat_r;      // uint2 [H][W]
     Buf hs, C, S;            // u16 [H][W1][D]
-    Buf disp, raw, mins;     // i16 [H][W]
+    Buf rec;                 // WTA records {disp16, raw, minS, 0} [H][W] x 8 bytes
+    bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
     Buf disp_lr, out;        // i16 [H][W]
     Buf rgb_l, rgb_r;        // u8 [H][W][3] input staging
     Buf rect_l, rect_r;      // u8 [H][W][3] rectified
@@ -124,9 +125,7 @@ int alloc_core(sv_ctx* c) {
     if ((rc = ensure(c, c->hs, nvol * 2))) return rc;
     if ((rc = ensure(c, c->C, nvol * 2))) return rc;
     if ((rc = ensure(c, c->S, nvol * 2))) return rc;
-    if ((rc = ensure(c, c->disp, npx * 2))) return rc;
-    if ((rc = ensure(c, c->raw, npx * 2))) return rc;
-    if ((rc = ensure(c, c->mins, npx * 2))) return rc;
+    if ((rc = ensure(c, c->rec, npx * 8))) return rc;
     if ((rc = ensure(c, c->disp_lr, npx * 2))) return rc;
     if ((rc = ensure(c, c->out, npx * 2))) return rc;
     return SV_OK;
@@ -145,7 +144,7 @@ struct DevGuard {
 };
 
 template <int N>
-void launch_agg_n(sv_ctx* c, int dir, bool first, int nb) {
+void launch_agg_n(sv_ctx* c, int dir, int mode, int nb) {
     static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
@@ -157,25 +156,38 @@ void launch_agg_n(sv_ctx* c, int dir, bool first, int nb) {
     const uint32_t* Cv = (const uint32_t*)c->C.p;
     uint32_t* Sv = (uint32_t*)c->S.p;
     constexpr int U = N <= 4 ? 4 : 2;
+    uint2* rec = (uint2*)c->rec.p;
+    const int uq = c->prm.uniqueness_ratio;
+#define SV_LAUNCH_AGG(V, M) \
+    hipLaunchKernelGGL((svk::k_agg<N, V, M, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2, rec, uq)
     if (vert) {
-        if (first) hipLaunchKernelGGL((svk::k_agg<N, true, true, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2);
-        else hipLaunchKernelGGL((svk::k_agg<N, true, false, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2);
+        switch (mode) {
+            case 0: SV_LAUNCH_AGG(true, 0); break;
+            case 1: SV_LAUNCH_AGG(true, 1); break;
+            case 2: SV_LAUNCH_AGG(true, 2); break;
+            default: SV_LAUNCH_AGG(true, 3); break;
+        }
     } else {
-        if (first) hipLaunchKernelGGL((svk::k_agg<N, false, true, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2);
-        else hipLaunchKernelGGL((svk::k_agg<N, false, false, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2);
+        switch (mode) {
+            case 0: SV_LAUNCH_AGG(false, 0); break;
+            case 1: SV_LAUNCH_AGG(false, 1); break;
+            case 2: SV_LAUNCH_AGG(false, 2); break;
+            default: SV_LAUNCH_AGG(false, 3); break;
+        }
     }
+#undef SV_LAUNCH_AGG
 }
 
-void launch_agg(sv_ctx* c, int dir, bool first, int nb) {
+void launch_agg(sv_ctx* c, int dir, int mode, int nb) {
     switch (c->prm.num_disparities / 32) {
-        case 1: launch_agg_n<1>(c, dir, first, nb); break;
-        case 2: launch_agg_n<2>(c, dir, first, nb); break;
-        case 3: launch_agg_n<3>(c, dir, first, nb); break;
-        case 4: launch_agg_n<4>(c, dir, first, nb); break;
-        case 5: launch_agg_n<5>(c, dir, first, nb); break;
-        case 6: launch_agg_n<6>(c, dir, first, nb); break;
-        case 7: launch_agg_n<7>(c, dir, first, nb); break;
-        default: launch_agg_n<8>(c, dir, first, nb); break;
+        case 1: launch_agg_n<1>(c, dir, mode, nb); break;
+        case 2: launch_agg_n<2>(c, dir, mode, nb); break;
+        case 3: launch_agg_n<3>(c, dir, mode, nb); break;
+        case 4: launch_agg_n<4>(c, dir, mode, nb); break;
+        case 5: launch_agg_n<5>(c, dir, mode, nb); break;
+        case 6: launch_agg_n<6>(c, dir, mode, nb); break;
+        case 7: launch_agg_n<7>(c, dir, mode, nb); break;
+        default: launch_agg_n<8>(c, dir, mode, nb); break;
     }
 }
 
@@ -183,8 +195,8 @@ template <int N>
 void launch_wta_n(sv_ctx* c, int nb) {
     const size_t npx = (size_t)c->W * c->H;
     const dim3 grid((unsigned)((npx * 16 + 255) / 256), nb), block(256);
-    hipLaunchKernelGGL((svk::k_wta<N>), grid, block, 0, c->stream, (const uint32_t*)c->S.p, (int16_t*)c->disp.p,
-                       (int16_t*)c->raw.p, (int16_t*)c->mins.p, c->W, c->H, c->prm.uniqueness_ratio);
+    hipLaunchKernelGGL((svk::k_wta<N>), grid, block, 0, c->stream, (const uint32_t*)c->S.p, (uint2*)c->rec.p, c->W, c->H,
+                       c->prm.uniqueness_ratio);
 }
 void launch_wta(sv_ctx* c, int nb) {
     switch (c->prm.num_disparities / 32) {
@@ -241,30 +253,31 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     }
     mark();
     // 3. path aggregation (first path initialises S)
+    // (first path initialises S; unless debugging, the last path carries WTA and never stores S)
     {
+        int last = 7;
+        while (!(p.path_mask & (1u << last))) last--;
         bool first = true;
         for (int dir = 0; dir < 8; dir++)
             if (p.path_mask & (1u << dir)) {
-                launch_agg(c, dir, first, nb);
+                launch_agg(c, dir, (first ? 1 : 0) | ((dir == last && !c->debug) ? 2 : 0), nb);
                 first = false;
             }
     }
     mark();
-    // 4. WTA
-    launch_wta(c, nb);
+    // 4. WTA (its own kernel only in debug mode)
+    if (c->debug) launch_wta(c, nb);
     mark();
     // 5. LR check, median, speckle
-    const int16_t* cur = (const int16_t*)c->disp.p;
-    if (!(p.flags & SV_FLAG_NO_LRCHECK)) {
+    {
+        // without the LR check the same kernel just unpacks the records (threshold that never trips)
         int thr = p.disp12_max_diff;
         if (p.flags & SV_FLAG_LR_OPENCV) thr = thr > 0 ? thr : 1;
-        hipLaunchKernelGGL(svk::k_lrcheck, dim3(H, nb), dim3(256), (size_t)W * 4, c->stream, cur, (const int16_t*)c->raw.p,
-                           (const int16_t*)c->mins.p, (int16_t*)c->disp_lr.p, W, D, thr);
-        cur = (const int16_t*)c->disp_lr.p;
-    } else {
-        HIPCHK(c, hipMemcpyAsync(c->disp_lr.p, cur, (size_t)W * H * 2 * nb, hipMemcpyDeviceToDevice, c->stream));
-        cur = (const int16_t*)c->disp_lr.p;
+        if (p.flags & SV_FLAG_NO_LRCHECK) thr = 1 << 20;
+        hipLaunchKernelGGL(svk::k_lrcheck, dim3(H, nb), dim3(256), (size_t)W * 4, c->stream, (const uint2*)c->rec.p,
+                           (int16_t*)c->disp_lr.p, W, D, thr);
     }
+    const int16_t* cur = (const int16_t*)c->disp_lr.p;
     if (!(p.flags & SV_FLAG_NO_MEDIAN)) {
         hipLaunchKernelGGL(svk::k_median3, dim3((W + 255) / 256, H, nb), dim3(256), 0, c->stream, cur, disp16, W, H,
                            (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
@@ -342,7 +355,7 @@ int sv_destroy(sv_ctx* c) {
         DevGuard g(c->device);
         if (g.ok) {
             (void)hipStreamSynchronize(c->stream);
-            Buf* all[] = {&c->img_l, &c->img_r, &c->stat_l, &c->stat_r, &c->hs, &c->C, &c->S, &c->disp, &c->raw, &c->mins,
+            Buf* all[] = {&c->img_l, &c->img_r, &c->stat_l, &c->stat_r, &c->hs, &c->C, &c->S, &c->rec,
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt};
@@ -573,8 +586,15 @@ int sv_depth_host(sv_ctx* c, const int16_t* d16, size_t dstride, const float* ma
     return SV_OK;
 }
 
+int sv_set_debug(sv_ctx* c, int enable) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    c->debug = enable != 0;
+    return SV_OK;
+}
+
 int sv_debug_read_volume_host(sv_ctx* c, int which, int16_t* vol, size_t n_elems) {
     if (!c) return SV_ERR_INVALID_ARG;
+    if (which == 1 && !c->debug) return fail(c, SV_ERR_INVALID_ARG, "S is only materialised in debug mode (sv_set_debug)");
     const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities;
     if (!vol || n_elems != nvol || which < 0 || which > 1) return fail(c, SV_ERR_INVALID_ARG, "bad volume request");
     DevGuard g(c->device);
@@ -586,10 +606,18 @@ int sv_debug_read_volume_host(sv_ctx* c, int which, int16_t* vol, size_t n_elems
 int sv_debug_read_plane_host(sv_ctx* c, int which, int16_t* plane) {
     if (!c) return SV_ERR_INVALID_ARG;
     if (!plane || which < 0 || which > 3) return fail(c, SV_ERR_INVALID_ARG, "bad plane request");
-    Buf* src[4] = {&c->disp, &c->raw, &c->mins, &c->disp_lr};
     DevGuard g(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(plane, src[which]->p, (size_t)c->W * c->H * 2, hipMemcpyDeviceToHost));
+    const size_t W = c->W, H = c->H;
+    if (which == 3) {
+        HIPCHK(c, hipMemcpy(plane, c->disp_lr.p, W * H * 2, hipMemcpyDeviceToHost));
+        return SV_OK;
+    }
+    // one int16 field of the 8-byte WTA records; columns [0, D) are never written by the fused path
+    HIPCHK(c, hipMemcpy2D(plane, 2, (const char*)c->rec.p + 2 * which, 8, 2, W * H, hipMemcpyDeviceToHost));
+    static const int16_t inval[3] = {SV_INVALID_DISP_SCALED, -1, 32767};
+    for (size_t y = 0; y < H; y++)
+        for (int x = 0; x < c->prm.num_disparities; x++) plane[y * W + x] = inval[which];
     return SV_OK;
 }
 

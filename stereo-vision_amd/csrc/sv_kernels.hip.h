@@ -240,6 +240,49 @@ __global__ __launch_bounds__(256) void k_vsum(const uint32_t* __restrict__ hs, u
 }
 
 // ---------------------------------------------------------------------------------------------
+// Winner-take-all + uniqueness + sub-pixel on one pixel's S held in the k_agg register layout
+// (16 lanes, lane q = disparities [q*2N, (q+1)*2N)).  Result of get_disparity
+// (aggregation.cu:629-689): first minimum wins (packed key S<<16|d under a DPP min), a pixel is
+// rejected if any d outside best+-1 has S*(100-uniq) < minS*100, sub-pixel by the parabola through
+// S[best-1], S[best], S[best+1] with C integer division.  Returns the 8-byte WTA record
+// {disp16, raw d (-1 = none), minS, 0}; every lane of the group gets the same record.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, int uniq) {
+    constexpr int D = 32 * N;
+    const int dbase = q * 2 * N;
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        key = min(key, ((s[k] & 0xFFFFu) << 16) | (uint32_t)(dbase + 2 * k));
+        key = min(key, (s[k] & 0xFFFF0000u) | (uint32_t)(dbase + 2 * k + 1));
+    }
+    key = row16_min_u32(key);
+    const int minS = (int)(key >> 16), best = (int)(key & 0xFFFFu);
+    uint32_t bad = 0, nb = 0;
+    const int thr = minS * 100, mul = 100 - uniq;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int d = dbase + 2 * k + h;
+            const int v = (int)(h ? (s[k] >> 16) : (s[k] & 0xFFFFu));
+            bad |= (v * mul < thr && abs(best - d) > 1) ? 1u : 0u;
+            nb |= (d == best - 1) ? ((uint32_t)v << 16) : 0u;
+            nb |= (d == best + 1) ? (uint32_t)v : 0u;
+        }
+    }
+    bad = row16_or_u32(bad);
+    nb = row16_or_u32(nb);
+    const int sm = (int)(nb >> 16), sp = (int)(nb & 0xFFFFu);
+    const int denom2 = max(sm + sp - 2 * minS, 1);
+    const int sub = (0 < best && best < D - 1) ? ((sm - sp) * 16 + denom2) / (denom2 * 2) : 0;
+    const bool ok = minS < 32767 && !bad;  // minS == 32767: every S saturated, no minimum
+    const int dv = ok ? best * 16 + sub : -16, rw = ok ? best : -1;
+    return make_uint2(((uint32_t)dv & 0xFFFFu) | ((uint32_t)rw << 16), (uint32_t)minS);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage 3: one SGM path.  Result of cost_aggregation_{lr,ud_lr,ud,rl_ud,rl}
 // (sgbm_cuda/aggregation.cu:60-625) and, with dy = -1, of the second sweep of MODE_HH:
 //   L(p,d) = C(p,d) + min(Lp(d), Lp(d-1)+P1, Lp(d+1)+P1, delta) - delta,  delta = min_d Lp + P2,
@@ -255,12 +298,18 @@ template <int N, int U>
 struct AggBatch {
     uint32_t c[U][N], s[U][N];
     size_t off[U];
+    uint32_t px[U];  // pixel index y*W + x + D of the step (LAST mode: where the WTA record goes)
     uint32_t rst;  // bit j: step j of the batch starts a fresh path; bit U: step 0 of the next batch does
 };
 
-template <int N, bool VERT, bool FIRST, int U>
+// MODE bit 0 (FIRST): this path initialises S (no read).  MODE bit 1 (LAST): this path does not
+// store S at all; the finished S of the pixel is still in registers, so WTA runs right here and
+// only the 8-byte WTA record leaves the kernel (saves one volume write and one volume read).
+template <int N, bool VERT, int MODE, int U>
 __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, int W1, int H, int dx,
-                                             int dy, uint32_t P1P1, uint32_t P2P2) {
+                                             int dy, uint32_t P1P1, uint32_t P2P2, uint2* __restrict__ rec, int uniq) {
+    constexpr bool FIRST = (MODE & 1) != 0, LAST = (MODE & 2) != 0;
+    const int W = W1 + 32 * N;
     const int q = threadIdx.x & 15;
     const int nchains = VERT ? W1 : H, nsteps = VERT ? H : W1;
     // Chains past the end repeat the last chain: same loads, same arithmetic, same stores from
@@ -272,6 +321,7 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
     const uint32_t laneoff = (uint32_t)q * N;
     C += (size_t)blockIdx.y * H * W1 * pxN;  // frame of a batched launch
     S += (size_t)blockIdx.y * H * W1 * pxN;
+    if (LAST) rec += (size_t)blockIdx.y * H * W;
 
     // load cursor (runs one batch ahead of the compute)
     int lx, ly;
@@ -285,6 +335,7 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
             // clamped: a prefetch that runs past the last step reads a valid (unused) pixel
             const int cy = min(max(ly, 0), H - 1), cx = min(max(lx, 0), W1 - 1);
             b.off[j] = ((size_t)cy * W1 + cx) * pxN + laneoff;
+            if (LAST) b.px[j] = (uint32_t)(cy * W + cx + 32 * N);
             load_regs<N>(C + b.off[j], b.c[j]);
             if (!FIRST) load_regs<N>(S + b.off[j], b.s[j]);
             if (VERT) {
@@ -305,7 +356,7 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
     for (int k = 0; k < N; k++) r[k] = 0;
     uint32_t dd = P2P2;
 
-    auto step = [&](const uint32_t (&c)[N], const uint32_t (&s)[N], size_t off, bool fresh) {
+    auto step = [&](const uint32_t (&c)[N], const uint32_t (&s)[N], size_t off, uint32_t px, bool fresh) {
         if (VERT) {
             const uint32_t keep = fresh ? 0u : 0xFFFFFFFFu;
 #pragma unroll
@@ -333,14 +384,15 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
         mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // both halves = lane minimum
         mn = row16_min_u32(mn);
         dd = mn + P2P2;  // halves cannot carry: min + P2 < 65536
-        store_regs<N>(S + off, snew);
+        if (LAST) rec[px] = wta_record<N>(snew, q, uniq);  // all 16 lanes store the same record
+        else store_regs<N>(S + off, snew);
     };
 
     uint32_t carry = 0;  // fresh-start flag for step 0 of the next batch
     auto compute = [&](AggBatch<N, U>& b) {
         const uint32_t flags = b.rst | carry;
 #pragma unroll
-        for (int j = 0; j < U; j++) step(b.c[j], b.s[j], b.off[j], (flags >> j) & 1u);
+        for (int j = 0; j < U; j++) step(b.c[j], b.s[j], b.off[j], b.px[j], (flags >> j) & 1u);
         carry = (b.rst >> U) & 1u;
     };
 
@@ -377,7 +429,7 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
 #pragma unroll
             for (int k = 0; k < N; k++) s[k] = 0;
         }
-        step(c, s, off, fresh);
+        step(c, s, off, (uint32_t)(y * W + x + 32 * N), fresh);
     }
 }
 
@@ -388,62 +440,20 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
 // raw = -1 marks "no disparity" (reference: INVALID_DISP_SCALED in d_raw_disp, :642).
 // ---------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, int16_t* __restrict__ disp,
-                                              int16_t* __restrict__ raw, int16_t* __restrict__ mins, int W, int H, int uniq) {
+__global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, uint2* __restrict__ rec, int W, int H, int uniq) {
     const int D = 32 * N, W1 = W - D;
     const int q = threadIdx.x & 15;
     const size_t pid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const size_t npx = (size_t)W * H;
-    const bool inimg = pid < npx;
-    const size_t p = inimg ? pid : npx - 1;
+    const size_t p = min(pid, npx - 1);  // surplus groups repeat the last pixel (same value, same wave)
     const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
     const int xl = max(x - D, 0);
     S += (size_t)blockIdx.y * H * W1 * 16 * N;
-    disp += (size_t)blockIdx.y * npx; raw += (size_t)blockIdx.y * npx; mins += (size_t)blockIdx.y * npx;
     uint32_t s[N];
     load_regs<N>(S + ((size_t)y * W1 + xl) * 16 * N + q * N, s);
-    const int dbase = q * 2 * N;
-    uint32_t key = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        key = min(key, ((s[k] & 0xFFFFu) << 16) | (uint32_t)(dbase + 2 * k));
-        key = min(key, (s[k] & 0xFFFF0000u) | (uint32_t)(dbase + 2 * k + 1));
-    }
-    key = row16_min_u32(key);
-    const int minS = (int)(key >> 16), best = (int)(key & 0xFFFFu);
-    uint32_t bad = 0, nb = 0;
-    const int thr = minS * 100, mul = 100 - uniq;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            int d = dbase + 2 * k + h;
-            int v = (int)(h ? (s[k] >> 16) : (s[k] & 0xFFFFu));
-            if (v * mul < thr && abs(best - d) > 1) bad = 1;
-            if (d == best - 1) nb |= (uint32_t)v << 16;
-            if (d == best + 1) nb |= (uint32_t)v;
-        }
-    }
-    bad = row16_or_u32(bad);
-    nb = row16_or_u32(nb);
-    if (q == 0 && inimg) {
-        int dv = -16, rw = -1, mv = 32767;
-        if (x >= D) {
-            mv = minS;
-            if (minS < 32767 && !bad) {
-                rw = best;
-                if (0 < best && best < D - 1) {
-                    int sm = (int)(nb >> 16), sp = (int)(nb & 0xFFFFu);
-                    int denom2 = max(sm + sp - 2 * minS, 1);
-                    dv = best * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
-                } else
-                    dv = best * 16;
-            }
-        }
-        disp[p] = (int16_t)dv;
-        raw[p] = (int16_t)rw;
-        mins[p] = (int16_t)mv;
-    }
+    uint2 r = wta_record<N>(s, q, uniq);
+    if (x < D) r = make_uint2(0xFFFFFFF0u, 32767u);  // {-16, -1, 32767}
+    rec[(size_t)blockIdx.y * npx + p] = r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -452,24 +462,22 @@ __global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, int
 // the larger x); the same winner is the minimum of the packed key (cost << 16 | 0xFFFF - x), so an
 // LDS atomicMin reproduces it without the serial scan.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lrcheck(const int16_t* __restrict__ disp, const int16_t* __restrict__ raw,
-                                                  const int16_t* __restrict__ mins, int16_t* __restrict__ out, int W, int D,
+__global__ __launch_bounds__(256) void k_lrcheck(const uint2* __restrict__ rec, int16_t* __restrict__ out, int W, int D,
                                                   int thresh) {
     extern __shared__ uint32_t keys[];
     const int y = blockIdx.x + blockIdx.y * gridDim.x;  // gridDim.x = H, blockIdx.y = frame
-    const int16_t* dp = disp + (size_t)y * W;
-    const int16_t* rw = raw + (size_t)y * W;
-    const int16_t* mn = mins + (size_t)y * W;
+    const uint2* rc = rec + (size_t)y * W;  // {disp16 | raw << 16, minS}; columns [0, D) are never read
     for (int x = threadIdx.x; x < W; x += blockDim.x) keys[x] = 0xFFFFFFFFu;
     __syncthreads();
     for (int x = D + threadIdx.x; x < W; x += blockDim.x) {
-        int d = rw[x];
-        if (d >= 0) atomicMin(&keys[x - d], ((uint32_t)(uint16_t)mn[x] << 16) | (uint32_t)(0xFFFF - x));
+        const uint2 r = rc[x];
+        const int d = (int)(int16_t)(r.x >> 16);
+        if (d >= 0) atomicMin(&keys[x - d], (r.y << 16) | (uint32_t)(0xFFFF - x));
     }
     __syncthreads();
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        int d1 = dp[x];
-        if (x >= D && d1 != -16) {
+        int d1 = x >= D ? (int)(int16_t)(rc[x].x & 0xFFFFu) : -16;
+        if (d1 != -16) {
             int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
             int _x = x - _d, x_ = x - d_;
             bool f1 = false, f2 = false;

@@ -29,7 +29,7 @@ EXPORTS = (
     "sv_compute_gray_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
-    "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
+    "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
     "sv_algorithmic_bytes", "sv_last_error", "sv_version")
 
 
@@ -96,6 +96,7 @@ def load():
     L.sv_filter_speckles_dev.argtypes = [vp, vp, i32, i32]
     L.sv_depth_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz]
     L.sv_depth_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.sv_set_debug.argtypes = [vp, i32]
     L.sv_debug_read_volume_host.argtypes = [vp, i32, vp, sz]
     L.sv_debug_read_plane_host.argtypes = [vp, i32, vp]
     L.sv_enable_timing.argtypes = [vp, i32]
@@ -214,6 +215,9 @@ class Matcher:
         self._chk(self._L.sv_depth_host(self._h, _ptr(d), 2 * self.W, _ptr(mapper), _ptr(Q), _ptr(R), _ptr(out),
                                         4 * self.W))
         return out
+
+    def set_debug(self, on=True):
+        self._chk(self._L.sv_set_debug(self._h, int(on)))
 
     def debug_volume(self, which):
         D = self.params.num_disparities

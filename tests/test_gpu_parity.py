@@ -35,6 +35,12 @@ def test_stages_bit_exact(gpu, W, H, D, paths, flags, bs, seed):
     ph, po = _params(D, paths, flags=flags, block_size=bs, P1=8 * bs * bs, P2=32 * bs * bs)
     ref, st = svref.sgbm(left, right, po, stages=("C", "S", "disp_wta", "raw", "mins", "disp_lr"))
     m = svhip.Matcher(W, H, ph)
+    fused = m.compute_gray(left, right)  # production path: WTA fused into the last path, S never stored
+    assert np.array_equal(fused, ref), "final disparity16 differs (fused WTA)"
+    assert np.array_equal(m.debug_plane(2), st["mins"]), "minS differs (fused WTA)"
+    assert np.array_equal(m.debug_plane(1), st["raw"]), "raw disparity differs (fused WTA)"
+    assert np.array_equal(m.debug_plane(0), st["disp_wta"]), "sub-pixel disparity differs (fused WTA)"
+    m.set_debug(True)                    # debug path: S materialised, WTA as its own kernel
     got = m.compute_gray(left, right)
     assert np.array_equal(m.debug_volume(0), st["C"]), "cost volume differs"
     assert np.array_equal(m.debug_volume(1), st["S"]), "aggregated volume differs"
@@ -53,6 +59,8 @@ def test_single_paths(gpu, mask):
     ph, po = _params(D, 8, path_mask=mask, flags=0)
     ref, st = svref.sgbm(left, right, po, stages=("S",))
     m = svhip.Matcher(W, H, ph)
+    assert np.array_equal(m.compute_gray(left, right), ref)
+    m.set_debug(True)
     got = m.compute_gray(left, right)
     assert np.array_equal(m.debug_volume(1), st["S"])
     assert np.array_equal(got, ref)
