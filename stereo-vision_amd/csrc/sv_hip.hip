@@ -35,7 +35,7 @@ struct sv_ctx {
     // device buffers
     Buf img_l, img_r;        // u8 [H][W] staging for the host entry points
     Buf stat_l, stat_r;      // uint2 [H][W]
-    Buf hs, C, S;            // u16 [H][W1][D]
+    Buf C, S;                // u16 [H][W1][D]
     Buf rec;                 // WTA records {disp16, raw, minS, 0} [H][W] x 8 bytes
     bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
     Buf disp_lr, out;        // i16 [H][W]
@@ -122,7 +122,6 @@ int alloc_core(sv_ctx* c) {
     int rc;
     if ((rc = ensure(c, c->stat_l, npx * 8))) return rc;
     if ((rc = ensure(c, c->stat_r, npx * 8))) return rc;
-    if ((rc = ensure(c, c->hs, nvol * 2))) return rc;
     if ((rc = ensure(c, c->C, nvol * 2))) return rc;
     if ((rc = ensure(c, c->S, nvol * 2))) return rc;
     if ((rc = ensure(c, c->rec, npx * 8))) return rc;
@@ -192,6 +191,42 @@ void launch_agg(sv_ctx* c, int dir, int mode, int nb) {
 }
 
 template <int N>
+int launch_cost_n(sv_ctx* c, int nb) {
+    const sv_params& p = c->prm;
+    const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
+    const svk::CostLds lay = svk::cost_lds_layout(D, r);
+    static bool attr_set[8] = {false};  // per N; the attribute is per kernel symbol (process-wide)
+    if (lay.total > 48 * 1024 && !attr_set[N - 1]) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_cost<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024));
+        attr_set[N - 1] = true;
+    }
+    // bands of rows: enough workgroups to fill 256 CUs, few enough that the 2r+1-row prologue stays small
+    int yband = 60;
+    while (yband > 24 && (size_t)((W1 + svk::COST_TX - 1) / svk::COST_TX) * ((H + yband - 1) / yband) * nb < 1024) yband -= 12;
+    const dim3 grid((W1 + svk::COST_TX - 1) / svk::COST_TX, (H + yband - 1) / yband, nb);
+    hipLaunchKernelGGL((svk::k_cost<N>), grid, dim3(256), (size_t)lay.total, c->stream, (const uint2*)c->stat_l.p,
+                       (const uint2*)c->stat_r.p, (uint32_t*)c->C.p, W, H, r, yband, (uint32_t)p.P2 * 0x10001u,
+                       (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0);
+    if (H > 1)
+        hipLaunchKernelGGL(svk::k_cost_col0, dim3(H - 1, nb), dim3(128), 0, c->stream, (uint32_t*)c->C.p, W1, H, D / 2,
+                           (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0);
+    return SV_OK;
+}
+int launch_cost(sv_ctx* c, int nb) {
+    switch (c->prm.num_disparities / 32) {
+        case 1: return launch_cost_n<1>(c, nb);
+        case 2: return launch_cost_n<2>(c, nb);
+        case 3: return launch_cost_n<3>(c, nb);
+        case 4: return launch_cost_n<4>(c, nb);
+        case 5: return launch_cost_n<5>(c, nb);
+        case 6: return launch_cost_n<6>(c, nb);
+        case 7: return launch_cost_n<7>(c, nb);
+        default: return launch_cost_n<8>(c, nb);
+    }
+}
+
+template <int N>
 void launch_wta_n(sv_ctx* c, int nb) {
     const size_t npx = (size_t)c->W * c->H;
     const dim3 grid((unsigned)((npx * 16 + 255) / 256), nb), block(256);
@@ -230,7 +265,7 @@ int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff, int nb) {
 // The matcher proper: device gray pair -> device disparity16.
 int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp16, int nb = 1) {
     const sv_params& p = c->prm;
-    const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
+    const int W = c->W, H = c->H, D = p.num_disparities;
     const bool tm = c->timing && c->ev_ok;
     int e = 0;
     hipEvent_t* evs = c->ev[c->ev_calls % sv_ctx::EV_RING];
@@ -242,14 +277,8 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     mark();
     // 2. matching cost volume C
     {
-        const int ncol = svk::COST_TX + 2 * r;
-        const size_t sm = (size_t)(svk::COST_TX + 10 + 256) * 8 + (size_t)(svk::COST_TX + 10) * 8 + (size_t)ncol * (D / 2) * 4;
-        hipLaunchKernelGGL(svk::k_pix_hsum, dim3((W1 + svk::COST_TX - 1) / svk::COST_TX, H, nb), dim3(256), sm, c->stream,
-                           (const uint2*)c->stat_l.p, (const uint2*)c->stat_r.p, (uint32_t*)c->hs.p, W, H, D, r);
-        const size_t rowN = (size_t)W1 * (D / 2);
-        hipLaunchKernelGGL(svk::k_vsum, dim3((unsigned)((rowN + 255) / 256), (H + svk::VSUM_BAND - 1) / svk::VSUM_BAND, nb), dim3(256),
-                           0, c->stream, (const uint32_t*)c->hs.p, (uint32_t*)c->C.p, W1, H, D, r, (uint32_t)p.P2 * 0x10001u,
-                           (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0);
+        int rc = launch_cost(c, nb);
+        if (rc) return rc;
     }
     mark();
     // 3. path aggregation (first path initialises S)
@@ -355,7 +384,7 @@ int sv_destroy(sv_ctx* c) {
         DevGuard g(c->device);
         if (g.ok) {
             (void)hipStreamSynchronize(c->stream);
-            Buf* all[] = {&c->img_l, &c->img_r, &c->stat_l, &c->stat_r, &c->hs, &c->C, &c->S, &c->rec,
+            Buf* all[] = {&c->img_l, &c->img_r, &c->stat_l, &c->stat_r, &c->C, &c->S, &c->rec,
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt};

@@ -136,107 +136,216 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t* __restrict__ left,
                                         (uint32_t)r0 | ((uint32_t)r1 << 8));
 }
 
-// BT cost of one (left pixel, right pixel) pair over both channels (costs.cu:180-199).
-__device__ __forceinline__ uint32_t bt_pair(uint2 l, uint2 r) {
-    int u = l.x & 0xff, u0 = (l.x >> 8) & 0xff, u1 = (l.x >> 16) & 0xff;
-    int v = r.x & 0xff, v0 = (r.x >> 8) & 0xff, v1 = (r.x >> 16) & 0xff;
-    int c0 = max(max(0, u - v1), v0 - u), c1 = max(max(0, v - u1), u0 - v);
-    int cost = min(c0, c1);
-    u = l.x >> 24; u0 = l.y & 0xff; u1 = (l.y >> 8) & 0xff;
-    v = r.x >> 24; v0 = r.y & 0xff; v1 = (r.y >> 8) & 0xff;
-    c0 = max(max(0, u - v1), v0 - u); c1 = max(max(0, v - u1), u0 - v);
-    return (uint32_t)(cost + (min(c0, c1) >> 2));
+// ---------------------------------------------------------------------------------------------
+// Stage 2: matching cost volume C, one fused kernel.  Result of get_pixel_diff x2 + get_hsum +
+// get_cost (costs.cu:170-284) without materialising pixDiff or hsum and without the two memsets:
+//   C[y][xl][d] = P2 + sum_{i=-r..r} sum_{k=-r..r} pix[max(y+i,0)][clamp(xl+k,0,W1-1)][d]
+// which is what the reference's running sums equal when no int16 store wraps (sv_check_params),
+// with its two quirks kept: the bottom SH2 rows repeat the last computed row (:279-282, or P2 with
+// SV_FLAG_C_TAIL_P2) and column x = D is overwritten afterwards by k_cost_col0 (:254-267).
+// A workgroup owns 16 columns x all D and marches down a band of rows.  Per image row it builds
+// the BT costs of its 16 + 2r columns in LDS as packed u16 pairs (packed 16-bit VALU: two
+// disparities per lane-op), takes the 2r+1-tap horizontal sum from LDS, keeps the last 2r+2
+// horizontal sums in an LDS ring and updates the vertical running sum in registers.  Thread
+// (xi = tid/16, q = tid%16) owns the same (column, N disparity pairs) as a k_agg lane, so C is
+// written with the 16-byte stores k_agg reads it back with.
+// ---------------------------------------------------------------------------------------------
+constexpr int COST_TX = 16;
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (ss2)(__builtin_bit_cast(ss2, a) - __builtin_bit_cast(ss2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b)));
+}
+// BT cost of one channel for two disparities at once (costs.cu:180-196): u* are the left pixel's
+// statistics duplicated in both halves, v* the right statistics of (x-d, x-d-1).
+__device__ __forceinline__ uint32_t bt_pk(uint32_t u, uint32_t u0, uint32_t u1, uint32_t v, uint32_t v0, uint32_t v1) {
+    const uint32_t c0 = pk_max_i16(pk_max_i16(pk_sub_i16(u, v1), pk_sub_i16(v0, u)), 0u);
+    const uint32_t c1 = pk_max_i16(pk_max_i16(pk_sub_i16(v, u1), pk_sub_i16(u0, v)), 0u);
+    return pk_min_i16(c0, c1);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Stage 2a: pixel cost + horizontal box sum, one (row, 32-column tile) per workgroup.
-// Result of get_pixel_diff x2 + get_hsum (costs.cu:170-233) without materialising pixDiff: the BT
-// costs of the tile plus its halo are built in LDS as packed u16 pairs and summed from there.
-// hs layout: [H][W1][D] u16, d innermost (same order as the reference volumes, common.h:23-25).
-// ---------------------------------------------------------------------------------------------
-constexpr int COST_TX = 32;
-__global__ __launch_bounds__(256) void k_pix_hsum(const uint2* __restrict__ stat_l, const uint2* __restrict__ stat_r,
-                                                   uint32_t* __restrict__ hs, int W, int H, int D, int radius) {
-    extern __shared__ __align__(16) uint32_t smem[];
-    const int W1 = W - D, D2 = D >> 1;
-    const int xl0 = blockIdx.x * COST_TX, y = blockIdx.y;
-    const int ncol = COST_TX + 2 * radius;
-    // R records for x in [rbase, rbase + nr)
-    const int xl_first = max(xl0 - radius, 0), xl_last = min(xl0 + COST_TX - 1 + radius, W1 - 1);
-    const int rbase = xl_first + 1;  // = (xl_first + D) - (D - 1)
-    const int nr = xl_last + D - rbase + 1;
-    uint2* Rs = reinterpret_cast<uint2*>(smem);
-    uint2* Ls = Rs + (COST_TX + 2 * 5 + 256);
-    uint32_t* pix = reinterpret_cast<uint32_t*>(Ls + (COST_TX + 2 * 5));  // [ncol][D2]
+struct CostLds {  // byte offsets into dynamic LDS
+    int lp, rv, pix, ring, total, nrv;
+};
+__host__ __device__ inline CostLds cost_lds_layout(int D, int radius) {
+    const int ncol = COST_TX + 2 * radius, D2 = D / 2, ringn = 2 * radius + 2;
+    CostLds L;
+    L.nrv = (ncol + D + 7) & ~3;
+    L.lp = 0;                                    // [ncol] x 32 B: six duplicated left statistics + pad
+    L.rv = L.lp + ncol * 32;                     // [4 copies][6 stats][nrv] u16, reversed in x
+    L.pix = (L.rv + 4 * 6 * L.nrv * 2 + 15) & ~15;  // [ncol][D2] u32
+    L.ring = L.pix + ncol * D2 * 4;              // [ringn][COST_TX][D2] u32
+    L.total = L.ring + ringn * COST_TX * D2 * 4;
+    return L;
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_cost(const uint2* __restrict__ stat_l, const uint2* __restrict__ stat_r,
+                                               uint32_t* __restrict__ C, int W, int H, int radius, int yband, uint32_t P2P2,
+                                               int tail_p2) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int D = 32 * N, D2 = 16 * N, D4 = 8 * N;
+    const int W1 = W - D, tid = threadIdx.x;
+    const int ncol = COST_TX + 2 * radius, nwin = 2 * radius + 1, ringn = 2 * radius + 2;
+    const CostLds lay = cost_lds_layout(D, radius);
+    const int nrv = lay.nrv;
+    unsigned char* Lp = smem_raw + lay.lp;
+    uint16_t* RV = reinterpret_cast<uint16_t*>(smem_raw + lay.rv);
+    uint32_t* pix = reinterpret_cast<uint32_t*>(smem_raw + lay.pix);
+    uint32_t* ring = reinterpret_cast<uint32_t*>(smem_raw + lay.ring);
+
+    const int xl0 = blockIdx.x * COST_TX;
+    const int y0 = blockIdx.y * yband, y1 = min(y0 + yband, H);
     const size_t fpx = (size_t)blockIdx.z * W * H;
-    const uint2* lrow = stat_l + fpx + (size_t)y * W;
-    const uint2* rrow = stat_r + fpx + (size_t)y * W;
-    hs += (size_t)blockIdx.z * H * W1 * D2;
-    for (int i = threadIdx.x; i < nr; i += blockDim.x) Rs[i] = rrow[rbase + i];
-    for (int j = threadIdx.x; j < ncol; j += blockDim.x) {
-        int xl = min(max(xl0 - radius + j, 0), W1 - 1);
-        Ls[j] = lrow[xl + D];
+    stat_l += fpx;
+    stat_r += fpx;
+    C += (size_t)blockIdx.z * H * W1 * D2;
+    const int xhi = min(xl0 + COST_TX - 1 + radius, W1 - 1) + D;  // largest left x of the tile (+halo)
+    const int xi = tid >> 4, q = tid & 15;
+    const int xl = xl0 + xi;
+    const bool colok = xl < W1;
+    uint32_t* myring = ring + xi * D2 + q * N;
+
+    // BT work items of a row: (tile column j, 4 consecutive disparities d0 = 4t..4t+3); the LDS
+    // addresses of an item do not depend on the row, so they are computed once.
+    // Right statistics sit in LDS reversed in x (index k <-> x = xhi - k, so d ascending = k
+    // ascending) in 4 copies shifted by 0..3 elements: whatever the column's offset, the four
+    // values k0..k0+3 are one aligned ds_read_b64 from copy (k0 & 3).
+    constexpr int MAXU = ((COST_TX + 10) * D4 + 255) / 256;
+    const int nitems = ncol * D4;
+    uint32_t a_lp[MAXU], a_rv[MAXU], a_px[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; i++) {
+        const int u = min(tid + 256 * i, nitems - 1);
+        const int j = u / D4, t = u - j * D4;
+        const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + D;
+        const int k0 = (xhi - xj) + 4 * t, c = k0 & 3;
+        a_lp[i] = (uint32_t)(j * 32);
+        a_rv[i] = (uint32_t)(((c * 6) * nrv + (k0 - c)) * 2);
+        a_px[i] = (uint32_t)((j * D2 + 2 * t) * 4);
     }
-    __syncthreads();
-    for (int it = threadIdx.x; it < ncol * D2; it += blockDim.x) {
-        int j = it / D2, dq = it - j * D2;
-        int xl = min(max(xl0 - radius + j, 0), W1 - 1);
-        int xr = xl + D - 2 * dq - rbase;  // index of x - d for d = 2*dq
-        uint2 l = Ls[j];
-        uint32_t a = bt_pair(l, Rs[xr]);
-        uint32_t b = bt_pair(l, Rs[xr - 1]);
-        pix[it] = a | (b << 16);
+
+    // The statistics of the NEXT image row are fetched into registers while the current row is
+    // being processed, so the global-load latency is off the per-row critical path.
+    constexpr int RPT = (COST_TX + 2 * 5 + D + 7 + 255) / 256;  // right records per thread (1 or 2)
+    uint2 pre_l = make_uint2(0u, 0u), pre_r[RPT];
+    auto prefetch = [&](int ry) {
+        ry = min(ry, H - 1);
+        const uint2* lrow = stat_l + (size_t)ry * W;
+        const uint2* rrow = stat_r + (size_t)ry * W;
+        if (tid < ncol) pre_l = lrow[min(max(xl0 - radius + tid, 0), W1 - 1) + D];
+#pragma unroll
+        for (int i = 0; i < RPT; i++) pre_r[i] = rrow[max(xhi - (tid + 256 * i), 0)];
+    };
+
+    // horizontal box sums of image row ry (whose statistics are in pre_l / pre_r) for this thread's
+    // (column, N pairs) -> hs[N], ring[ry]
+    auto hs_row = [&](int ry, uint32_t (&hs)[N]) {
+        __syncthreads();  // previous row's pix / statistics fully consumed
+        if (tid < ncol) {
+            const uint2 r = pre_l;
+            uint4 a;
+            a.x = (r.x & 0xFFu) * 0x10001u;          // g
+            a.y = ((r.x >> 8) & 0xFFu) * 0x10001u;   // g0
+            a.z = ((r.x >> 16) & 0xFFu) * 0x10001u;  // g1
+            a.w = (r.x >> 24) * 0x10001u;            // r
+            *reinterpret_cast<uint4*>(Lp + tid * 32) = a;
+            *reinterpret_cast<uint2*>(Lp + tid * 32 + 16) = make_uint2((r.y & 0xFFu) * 0x10001u, ((r.y >> 8) & 0xFFu) * 0x10001u);
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+            const int k = tid + 256 * i;
+            if (k < nrv) {
+                const uint2 r = pre_r[i];
+                const uint16_t st[6] = {(uint16_t)(r.x & 0xFFu), (uint16_t)((r.x >> 8) & 0xFFu), (uint16_t)((r.x >> 16) & 0xFFu),
+                                        (uint16_t)(r.x >> 24), (uint16_t)(r.y & 0xFFu), (uint16_t)((r.y >> 8) & 0xFFu)};
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (k >= c) {
+#pragma unroll
+                        for (int s = 0; s < 6; s++) RV[(c * 6 + s) * nrv + k - c] = st[s];
+                    }
+            }
+        }
+        prefetch(ry + 1);
+        __syncthreads();
+        const unsigned char* RVb = reinterpret_cast<const unsigned char*>(RV);
+#pragma unroll
+        for (int i = 0; i < MAXU; i++) {
+            if (tid + 256 * i < nitems) {
+                const uint4 la = *reinterpret_cast<const uint4*>(Lp + a_lp[i]);
+                const uint2 lb = *reinterpret_cast<const uint2*>(Lp + a_lp[i] + 16);
+                const unsigned char* rv = RVb + a_rv[i];
+                const uint2 v = *reinterpret_cast<const uint2*>(rv);
+                const uint2 v0 = *reinterpret_cast<const uint2*>(rv + nrv * 2);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(rv + nrv * 4);
+                const uint2 w = *reinterpret_cast<const uint2*>(rv + nrv * 6);
+                const uint2 w0 = *reinterpret_cast<const uint2*>(rv + nrv * 8);
+                const uint2 w1 = *reinterpret_cast<const uint2*>(rv + nrv * 10);
+                // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
+                const uint32_t p0 = bt_pk(la.x, la.y, la.z, v.x, v0.x, v1.x) + ((bt_pk(la.w, lb.x, lb.y, w.x, w0.x, w1.x) >> 2) & 0x3FFF3FFFu);
+                const uint32_t p1 = bt_pk(la.x, la.y, la.z, v.y, v0.y, v1.y) + ((bt_pk(la.w, lb.x, lb.y, w.y, w0.y, w1.y) >> 2) & 0x3FFF3FFFu);
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(pix) + a_px[i]) = make_uint2(p0, p1);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < N; k++) hs[k] = 0;
+        for (int t = 0; t < nwin; t++) {
+            uint32_t v[N];
+            load_regs<N>(pix + (xi + t) * D2 + q * N, v);
+#pragma unroll
+            for (int k = 0; k < N; k++) hs[k] += v[k];  // <= 189 * 11 per half: no carry
+        }
+        store_regs<N>(myring + (ry % ringn) * (COST_TX * D2), hs);
+    };
+
+    const int ylast = H - 1 - radius;
+    const int ys = min(y0, ylast);
+    uint32_t acc[N], hs[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) acc[k] = 0;
+    prefetch(max(ys - radius, 0));
+    for (int ry = max(ys - radius, 0); ry <= ys + radius; ry++) {
+        hs_row(ry, hs);
+        const uint32_t mult = ry == 0 ? (uint32_t)(radius - ys + 1) : 1u;  // row 0 stands for every row above it
+#pragma unroll
+        for (int k = 0; k < N; k++) acc[k] += hs[k] * mult;
     }
-    __syncthreads();
-    const int nwin = 2 * radius + 1;
-    for (int it = threadIdx.x; it < COST_TX * D2; it += blockDim.x) {
-        int xi = it / D2, dq = it - xi * D2;
-        int xl = xl0 + xi;
-        if (xl >= W1) break;
-        uint32_t acc = 0;  // packed halves cannot carry: 189 * 11 < 65536
-        for (int k = 0; k < nwin; k++) acc += pix[(xi + k) * D2 + dq];
-        hs[((size_t)y * W1 + xl) * D2 + dq] = acc;
+    uint32_t* Cout = C + (size_t)xl * D2 + q * N;
+    const size_t rowN = (size_t)W1 * D2;
+    for (int y = y0; y < y1; y++) {
+        uint32_t out[N];
+        if (y <= ylast) {
+            if (y > ys) {
+                hs_row(y + radius, hs);
+                uint32_t old[N];
+                load_regs<N>(myring + (max(y - radius - 1, 0) % ringn) * (COST_TX * D2), old);
+#pragma unroll
+                for (int k = 0; k < N; k++) acc[k] = acc[k] + hs[k] - old[k];
+            }
+#pragma unroll
+            for (int k = 0; k < N; k++) out[k] = acc[k] + P2P2;
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; k++) out[k] = tail_p2 ? P2P2 : acc[k] + P2P2;
+        }
+        if (colok) store_regs<N>(Cout + (size_t)y * rowN, out);
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Stage 2b: vertical box sum + P2.  Result of get_cost (costs.cu:235-284) written as the clamped
-// window sum it equals when no int16 store wraps (guaranteed by sv_check_params), with the two
-// quirks kept: column x = D repeats row 0 (:254-267) and the bottom SH2 rows repeat the last
-// computed row (:279-282); the SV_FLAG_C_*_P2 flags select the MODE_HH alternatives.
-// One thread owns one packed (xl, d-pair) and marches down a band of rows with a running sum.
-// ---------------------------------------------------------------------------------------------
-constexpr int VSUM_BAND = 32;
-__global__ __launch_bounds__(256) void k_vsum(const uint32_t* __restrict__ hs, uint32_t* __restrict__ C, int W1, int H,
-                                               int D, int radius, uint32_t P2P2, int col0_p2, int tail_p2) {
-    const int D2 = D >> 1;
-    const size_t rowN = (size_t)W1 * D2;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rowN) return;
-    const int y0 = blockIdx.y * VSUM_BAND, y1 = min(y0 + VSUM_BAND, H);
-    const int ylast = H - 1 - radius;
-    const bool col0 = e < (size_t)D2;
-    hs += (size_t)blockIdx.z * H * rowN;
-    C += (size_t)blockIdx.z * H * rowN;
-    const int ys = min(y0, ylast);
-    uint32_t acc = 0;
-    for (int k = -radius; k <= radius; k++) acc += hs[(size_t)max(ys + k, 0) * rowN + e];
-    uint32_t row0 = 0;
-    if (col0) {
-        for (int k = -radius; k <= radius; k++) row0 += hs[(size_t)max(k, 0) * rowN + e];
-        row0 += P2P2;
-    }
-    for (int y = y0; y < y1; y++) {
-        uint32_t val;
-        if (y <= ylast) {
-            if (y > ys) acc = acc + hs[(size_t)(y + radius) * rowN + e] - hs[(size_t)max(y - radius - 1, 0) * rowN + e];
-            val = acc + P2P2;
-        } else {
-            val = tail_p2 ? P2P2 : acc + P2P2;
-        }
-        if (col0 && y > 0) val = col0_p2 ? P2P2 : row0;
-        C[(size_t)y * rowN + e] = val;
-    }
+// Column x = D of C (local column 0): "copy opencv" quirk, costs.cu:254-267 — every row repeats row
+// 0 (REPO) or holds the initial P2 (MODE_HH, SV_FLAG_C_COL0_P2).  Runs after k_cost.
+__global__ __launch_bounds__(256) void k_cost_col0(uint32_t* __restrict__ C, int W1, int H, int D2, uint32_t P2P2, int col0_p2) {
+    const int dq = threadIdx.x, y = blockIdx.x + 1;
+    if (dq >= D2 || y >= H) return;
+    C += (size_t)blockIdx.y * H * W1 * D2;
+    C[(size_t)y * W1 * D2 + dq] = col0_p2 ? P2P2 : C[dq];
 }
 
 // ---------------------------------------------------------------------------------------------
