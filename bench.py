@@ -76,6 +76,18 @@ def cpu_baseline(W, H, D, paths, left, right, budget_s=12.0):
     return out
 
 
+def pmc_traffic(config, batch):
+    """HBM bytes per k_agg launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this workload, gfx950 FETCH_SIZE x2 correction applied);
+    None when no pass was collected for this config/batch."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f).get("%s_b%d" % (config, batch))
+        return int(t["traffic_bytes_per_launch"]) if t else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,7 +185,7 @@ def main():
             "frame_roofline_frac": round(frame_bytes * (fps / world) / (HBM_PEAK_GBS * 1e9), 4),
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": "svk::k_agg", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, B),
                          "launch_us": round(launch_s * 1e6, 2), "bytes_per_launch": agg_bytes_per_launch},
         }
         if not args.no_cpu_baseline:
