@@ -186,6 +186,24 @@ int sv_disparity_vis_host(sv_ctx* ctx, const int16_t* disp16_host, uint8_t* vis_
  * matchSGBM, StereoMatcher.cpp:412) on a device disparity16 image, in place.  */
 int sv_filter_speckles_dev(sv_ctx* ctx, int16_t* disp16_dev, int max_size, int max_diff);
 
+/* Replaces the two wls_filter->filter(...) calls of StereoMatcherNew::filterWLS
+ * (StereoMatcher.cpp:154-160) on the filter made by
+ * createDisparityWLSFilterGeneric(false) (StereoMatcher.cpp:265): outside the
+ * ROI of computeROI2 (StereoMatcher.cpp:12-29; sv_wls_roi returns {x,y,w,h})
+ * the output is -16 (0 in the 8-bit image), inside it is the fast global
+ * smoother (3 iterations, lambda x0.25 each) of the input guided by the
+ * rectified left RGB image; lambda / sigma come from sv_params.  The 16-bit
+ * map and, when vis != NULL, its 8-bit visualisation are filtered together,
+ * as are the n_frames dense-packed frames of a batch.
+ * _host: guide_rgb_host == NULL uses the rectified left image kept on the
+ * device by the last sv_compute_rgb_host.                                     */
+int sv_wls_roi(const sv_ctx* ctx, int* roi_xywh);
+int sv_filter_wls_dev(sv_ctx* ctx, int n_frames, const int16_t* disp16_dev, const uint8_t* vis_dev,
+                      const uint8_t* guide_rgb_dev, int16_t* disp16_wls_dev, uint8_t* vis_wls_dev);
+int sv_filter_wls_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride, const uint8_t* vis_host,
+                       size_t vis_stride, const uint8_t* guide_rgb_host, size_t guide_stride,
+                       int16_t* disp16_wls_host, size_t out16_stride, uint8_t* vis_wls_host, size_t out8_stride);
+
 /* Replaces DispModule::depthFromDisparity (DispModule.cpp:320-366), with the
  * non-aliased read.  mapper = MapperL (CV_32FC2,
  * width*height*2 floats), Q 4x4 and R 3x3 row-major doubles, host memory.     */

@@ -526,3 +526,115 @@ void svref_depth(const int16_t* disp16, int W, int H, const float* mapper, const
         }
     if (!alias) free(src);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * A15 (EXT).  WLS post-filter: what StereoMatcherNew::filterWLS asks of
+ * cv::ximgproc::createDisparityWLSFilterGeneric(false) (StereoMatcher.cpp:127-198, ctor :265):
+ * no confidence map, so DisparityWLSFilterImpl::filter reduces to
+ *   dst = 16*(min_disp-1) everywhere (min_disp = 0 in the Generic factory), then
+ *   dst(ROI) = fastGlobalSmootherFilter(guide(ROI), disp(ROI), lambda, sigma_color)
+ * with lambda_attenuation 0.25 and 3 iterations (the defaults of fastGlobalSmootherFilter),
+ * the input converted to float, and the result converted back with saturate_cast(cvRound).
+ * The fast global smoother (Min et al. 2014) alternates, per iteration, one tridiagonal solve
+ * along every row and one along every column of (I + lambda*A) u = f, A the 1-D Laplacian with
+ * edge weights exp(-|dI|/sigma) taken from a table indexed by the squared colour distance;
+ * lambda is multiplied by the attenuation after each iteration.  OpenCV is not installed, so
+ * the operation order below (Thomas algorithm, float) is this oracle's and "parity unpinned".
+ * ------------------------------------------------------------------------------------------ */
+#define SVREF_WLS_LUT_SIZE (3 * 256 * 256)
+
+void svref_wls_lut(float sigma, float* lut) {
+    for (int i = 0; i < SVREF_WLS_LUT_SIZE; i++) lut[i] = -expf(-sqrtf((float)i) / sigma);
+}
+
+/* computeROI2, StereoMatcher.cpp:12-29 */
+void svref_wls_roi(int W, int H, const svref_params* p, int roi[4]) {
+    const int bs2 = p->block_size / 2;
+    const int minD = p->min_disparity, maxD = p->min_disparity + p->num_disparities - 1;
+    const int xmin = maxD + bs2, xmax = W + minD - bs2, ymin = bs2, ymax = H - bs2;
+    roi[0] = xmin; roi[1] = ymin; roi[2] = xmax - xmin; roi[3] = ymax - ymin;
+}
+
+/* one Thomas solve over n samples with stride `st`; w[k*st] is the (negative) weight between
+ * sample k and k+1 (0 for the last), tmp receives the modified super-diagonal */
+static void fgs_solve(float* cur, const float* w, float* tmp, int n, size_t st, float lambda) {
+    float coef_cur = lambda * w[0];
+    float denom = 1.0f - coef_cur;
+    tmp[0] = coef_cur / denom;
+    cur[0] = cur[0] / denom;
+    for (int k = 1; k < n; k++) {
+        const float coef_prev = lambda * w[(size_t)(k - 1) * st];
+        coef_cur = lambda * w[(size_t)k * st];
+        denom = (1.0f - coef_prev - coef_cur) - coef_prev * tmp[(size_t)(k - 1) * st];
+        tmp[(size_t)k * st] = coef_cur / denom;
+        cur[(size_t)k * st] = (cur[(size_t)k * st] - coef_prev * cur[(size_t)(k - 1) * st]) / denom;
+    }
+    for (int k = n - 2; k >= 0; k--) cur[(size_t)k * st] = cur[(size_t)k * st] - tmp[(size_t)k * st] * cur[(size_t)(k + 1) * st];
+}
+
+/* fastGlobalSmootherFilter on a float image [h][w] in place; guide is 8UC3 with row stride gs */
+int svref_fgs(const uint8_t* guide, size_t gs, float* img, int w, int h, float lambda, float sigma, float att,
+              int iters) {
+    if (w < 1 || h < 1 || !(sigma > 0) || !(lambda >= 0) || iters < 1) return -1;
+    const size_t n = (size_t)w * h;
+    float* lut = (float*)malloc(sizeof(float) * SVREF_WLS_LUT_SIZE);
+    float* ch = (float*)malloc(sizeof(float) * n);
+    float* cv = (float*)malloc(sizeof(float) * n);
+    float* tmp = (float*)malloc(sizeof(float) * n);
+    if (!lut || !ch || !cv || !tmp) { free(lut); free(ch); free(cv); free(tmp); return -2; }
+    svref_wls_lut(sigma, lut);
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            const uint8_t* p = guide + (size_t)i * gs + 3 * (size_t)j;
+            float wh = 0.0f, wv = 0.0f;
+            if (j < w - 1) {
+                const uint8_t* q = p + 3;
+                wh = lut[(p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2])];
+            }
+            if (i < h - 1) {
+                const uint8_t* q = p + gs;
+                wv = lut[(p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2])];
+            }
+            ch[(size_t)i * w + j] = wh;
+            cv[(size_t)i * w + j] = wv;
+        }
+    float lam = lambda;
+    for (int it = 0; it < iters; it++) {
+        for (int i = 0; i < h; i++) fgs_solve(img + (size_t)i * w, ch + (size_t)i * w, tmp + (size_t)i * w, w, 1, lam);
+        for (int j = 0; j < w; j++) fgs_solve(img + j, cv + j, tmp + j, h, (size_t)w, lam);
+        lam *= att;
+    }
+    free(lut); free(ch); free(cv); free(tmp);
+    return 0;
+}
+
+/* filterWLS on the 16-bit map (StereoMatcher.cpp:160) and, when vis != NULL, on the 8-bit
+ * visualisation (:159).  guide = rectified left image, 8UC3 dense.  roi = {x, y, w, h}.     */
+int svref_wls_filter(const int16_t* disp16, const uint8_t* vis, const uint8_t* guide_rgb, int W, int H, const int roi[4],
+                     float lambda, float sigma, int16_t* out16, uint8_t* out8) {
+    const int rx = roi[0], ry = roi[1], rw = roi[2], rh = roi[3];
+    if (rx < 0 || ry < 0 || rw < 1 || rh < 1 || rx + rw > W || ry + rh > H) return -1;
+    float* buf = (float*)malloc(sizeof(float) * (size_t)rw * rh);
+    if (!buf) return -2;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1 && (!vis || !out8)) break;
+        for (int i = 0; i < rh; i++)
+            for (int j = 0; j < rw; j++) {
+                const size_t o = (size_t)(ry + i) * W + rx + j;
+                buf[(size_t)i * rw + j] = pass == 0 ? (float)disp16[o] : (float)vis[o];
+            }
+        int rc = svref_fgs(guide_rgb + ((size_t)ry * W + rx) * 3, (size_t)W * 3, buf, rw, rh, lambda, sigma, 0.25f, 3);
+        if (rc) { free(buf); return rc; }
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const size_t o = (size_t)y * W + x;
+                const int in = x >= rx && x < rx + rw && y >= ry && y < ry + rh;
+                const float f = in ? buf[(size_t)(y - ry) * rw + (x - rx)] : -16.0f;
+                long r = lrintf(f);  /* cvRound: round half to even */
+                if (pass == 0) out16[o] = (int16_t)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+                else out8[o] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+            }
+    }
+    free(buf);
+    return 0;
+}

@@ -98,6 +98,14 @@ void svref_remap_rgb(const uint8_t* src, int W, int H, const float* mapx, const 
 void svref_depth(const int16_t* disp16, int W, int H, const float* mapper, const double* Q, const double* R,
                  int alias, float* depth);
 
+/* A15 (EXT createDisparityWLSFilterGeneric(false) -> fastGlobalSmootherFilter), StereoMatcher.cpp:127-198 */
+void svref_wls_lut(float sigma, float* lut /* [3*256*256] */);
+void svref_wls_roi(int W, int H, const svref_params* p, int roi[4]); /* computeROI2, StereoMatcher.cpp:12-29 */
+int svref_fgs(const uint8_t* guide, size_t gs, float* img, int w, int h, float lambda, float sigma, float att,
+              int iters);
+int svref_wls_filter(const int16_t* disp16, const uint8_t* vis, const uint8_t* guide_rgb, int W, int H, const int roi[4],
+                     float lambda, float sigma, int16_t* out16, uint8_t* out8);
+
 const char* svref_version(void);
 #ifdef __cplusplus
 }

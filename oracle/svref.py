@@ -89,6 +89,14 @@ def lib():
         L.svref_depth.restype = None
         L.svref_depth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_void_p]
+        L.svref_wls_lut.restype = None
+        L.svref_wls_lut.argtypes = [C.c_float, C.c_void_p]
+        L.svref_wls_roi.restype = None
+        L.svref_wls_roi.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_int * 4)]
+        L.svref_fgs.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                C.c_int]
+        L.svref_wls_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int * 4),
+                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -208,3 +216,45 @@ def depth(disp16, mapper, Q, R, alias=False):
     out = np.empty((H, W), np.float32)
     lib().svref_depth(_ptr(d), W, H, _ptr(mapper), _ptr(Q), _ptr(R), int(alias), _ptr(out))
     return out
+
+
+def wls_roi(W, H, params):
+    """computeROI2 (StereoMatcher.cpp:12-29): (x, y, w, h)."""
+    r = (C.c_int * 4)()
+    lib().svref_wls_roi(W, H, C.byref(params), C.byref(r))
+    return tuple(r)
+
+
+def wls_lut(sigma):
+    out = np.empty(3 * 256 * 256, np.float32)
+    lib().svref_wls_lut(sigma, _ptr(out))
+    return out
+
+
+def fgs(guide_rgb, img, lam, sigma, att=0.25, iters=3):
+    """fastGlobalSmootherFilter on a float32 image with an 8UC3 guide of the same size."""
+    g = np.ascontiguousarray(guide_rgb, np.uint8)
+    out = np.ascontiguousarray(img, np.float32).copy()
+    h, w = out.shape
+    assert g.shape == (h, w, 3)
+    rc = lib().svref_fgs(_ptr(g), 3 * w, _ptr(out), w, h, lam, sigma, att, iters)
+    if rc:
+        raise ValueError("svref_fgs failed: %d" % rc)
+    return out
+
+
+def wls_filter(disp16, guide_rgb, roi, lam, sigma, vis=None):
+    """filterWLS (StereoMatcher.cpp:154-160): returns disp16_wls (and vis_wls when vis is given)."""
+    d = np.ascontiguousarray(disp16, np.int16)
+    g = np.ascontiguousarray(guide_rgb, np.uint8)
+    H, W = d.shape
+    assert g.shape == (H, W, 3)
+    out16 = np.empty((H, W), np.int16)
+    v = np.ascontiguousarray(vis, np.uint8) if vis is not None else None
+    out8 = np.empty((H, W), np.uint8) if vis is not None else None
+    r = (C.c_int * 4)(*roi)
+    rc = lib().svref_wls_filter(_ptr(d), _ptr(v) if v is not None else None, _ptr(g), W, H, C.byref(r), lam, sigma,
+                                _ptr(out16), _ptr(out8) if out8 is not None else None)
+    if rc:
+        raise ValueError("svref_wls_filter failed: %d" % rc)
+    return (out16, out8) if vis is not None else out16

@@ -10,8 +10,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "sv_kernels.hip.h"
 
@@ -48,6 +50,9 @@ struct sv_ctx {
     Buf d16tmp;              // i16 [H][W] staging for host helper entry points
     Buf vis;                 // u8 [H][W]
     Buf lab, cnt;            // int [H][W] speckle union-find
+    Buf wls_lut, wls_wh, wls_wv, wls_cur, wls_tmp;  // WLS: weight table, edge weights, work images (float)
+    Buf wls_g, wls_v, wls_o16, wls_o8;              // WLS host entry point staging
+    float wls_lut_sigma = -1.0f;                    // sigma the device table was built for
     bool have_maps = false;
 
     // stage timing: a ring of event sets, one set per compute call, read back (and averaged)
@@ -262,6 +267,62 @@ int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff, int nb) {
     return SV_OK;
 }
 
+// computeROI2 (StereoMatcher.cpp:12-29)
+void wls_roi(const sv_ctx* c, int roi[4]) {
+    const int bs2 = c->prm.block_size / 2;
+    const int minD = c->prm.min_disparity, maxD = minD + c->prm.num_disparities - 1;
+    roi[0] = maxD + bs2;
+    roi[1] = bs2;
+    roi[2] = (c->W + minD - bs2) - roi[0];
+    roi[3] = (c->H - bs2) - roi[1];
+}
+
+// filterWLS (StereoMatcher.cpp:154-160) on nf dense-packed frames; vis/out8 may be NULL.
+int wls_dev(sv_ctx* c, int nf, const int16_t* d16, const uint8_t* vis, const uint8_t* guide, int16_t* out16, uint8_t* out8) {
+    const int W = c->W, H = c->H;
+    int roi[4];
+    wls_roi(c, roi);
+    const int rx = roi[0], ry = roi[1], rw = roi[2], rh = roi[3];
+    if (rw < 1 || rh < 1) return fail(c, SV_ERR_INVALID_ARG, "empty WLS ROI %dx%d (image too small for D and block size)", rw, rh);
+    const float lambda = c->prm.wls_lambda, sigma = c->prm.wls_sigma;
+    if (!(lambda >= 0.0f) || !(sigma > 0.0f)) return fail(c, SV_ERR_INVALID_ARG, "need wls_lambda >= 0 and wls_sigma > 0");
+    const int K = (vis && out8) ? 2 : 1, nimg = nf * K;
+    const size_t nroi = (size_t)rw * rh;
+    int rc;
+    if ((rc = ensure(c, c->wls_lut, sizeof(float) * svk::WLS_LUT_SIZE))) return rc;
+    if ((rc = ensure(c, c->wls_wh, sizeof(float) * nroi * nf))) return rc;
+    if ((rc = ensure(c, c->wls_wv, sizeof(float) * nroi * nf))) return rc;
+    if ((rc = ensure(c, c->wls_cur, sizeof(float) * nroi * nimg))) return rc;
+    if ((rc = ensure(c, c->wls_tmp, sizeof(float) * nroi * nimg))) return rc;
+    if (c->wls_lut_sigma != sigma) {
+        // weight table of the fast global smoother: -exp(-sqrt(squared colour distance) / sigma), built
+        // on the host in float (as the CPU statement does) so that both sides share every bit of it
+        std::vector<float> lut(svk::WLS_LUT_SIZE);
+        for (int i = 0; i < svk::WLS_LUT_SIZE; i++) lut[i] = -expf(-sqrtf((float)i) / sigma);
+        HIPCHK(c, hipMemcpyAsync(c->wls_lut.p, lut.data(), sizeof(float) * lut.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // lut is a local
+        c->wls_lut_sigma = sigma;
+    }
+    float* cur = (float*)c->wls_cur.p;
+    float* tmp = (float*)c->wls_tmp.p;
+    float* wh = (float*)c->wls_wh.p;
+    float* wv = (float*)c->wls_wv.p;
+    const dim3 b(256);
+    hipLaunchKernelGGL(svk::k_wls_weights, dim3((rw + 255) / 256, rh, nf), b, 0, c->stream, guide, (const float*)c->wls_lut.p, wh,
+                       wv, W, H, rx, ry, rw, rh);
+    hipLaunchKernelGGL(svk::k_wls_load, dim3((rw + 255) / 256, rh, nimg), b, 0, c->stream, d16, vis, cur, W, H, rx, ry, rw, rh, K);
+    float lam = lambda;
+    for (int it = 0; it < 3; it++) {  // fastGlobalSmootherFilter defaults: 3 iterations, attenuation 0.25
+        hipLaunchKernelGGL(svk::k_fgs_hpass, dim3((rh + svk::FGS_T - 1) / svk::FGS_T, nimg), dim3(64), 0, c->stream, cur, wh, tmp,
+                           rw, rh, K, lam);
+        hipLaunchKernelGGL(svk::k_fgs_vpass, dim3((rw + 63) / 64, nimg), dim3(64), 0, c->stream, cur, wv, tmp, rw, rh, K, lam);
+        lam *= 0.25f;
+    }
+    hipLaunchKernelGGL(svk::k_wls_store, dim3((W + 255) / 256, H, nimg), b, 0, c->stream, cur, out16, out8, W, H, rx, ry, rw, rh, K);
+    HIPCHK(c, hipGetLastError());
+    return SV_OK;
+}
+
 // The matcher proper: device gray pair -> device disparity16.
 int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp16, int nb = 1) {
     const sv_params& p = c->prm;
@@ -387,7 +448,8 @@ int sv_destroy(sv_ctx* c) {
             Buf* all[] = {&c->img_l, &c->img_r, &c->stat_l, &c->stat_r, &c->C, &c->S, &c->rec,
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->depth, &c->d16tmp, &c->vis,
-                          &c->lab, &c->cnt};
+                          &c->lab, &c->cnt, &c->wls_lut, &c->wls_wh, &c->wls_wv, &c->wls_cur, &c->wls_tmp, &c->wls_g,
+                          &c->wls_v, &c->wls_o16, &c->wls_o8};
             for (Buf* b : all) release(*b);
             if (c->ev_ok)
                 for (int r = 0; r < sv_ctx::EV_RING; r++)
@@ -611,6 +673,57 @@ int sv_depth_host(sv_ctx* c, const int16_t* d16, size_t dstride, const float* ma
     HIPCHK(c, hipMemcpyAsync(c->mapper.p, mapper, W * H * 8, hipMemcpyHostToDevice, c->stream));
     if ((rc = sv_depth_dev(c, (const int16_t*)c->d16tmp.p, (const float*)c->mapper.p, Q, R, (float*)c->depth.p))) return rc;
     HIPCHK(c, hipMemcpy2DAsync(depth, ostride, c->depth.p, 4 * W, 4 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_wls_roi(const sv_ctx* c, int* roi) {
+    if (!c || !roi) return SV_ERR_INVALID_ARG;
+    wls_roi(c, roi);
+    return SV_OK;
+}
+
+int sv_filter_wls_dev(sv_ctx* c, int n_frames, const int16_t* d16, const uint8_t* vis, const uint8_t* guide, int16_t* out16,
+                      uint8_t* out8) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !guide || !out16 || n_frames < 1) return fail(c, SV_ERR_INVALID_ARG, "bad WLS argument");
+    if ((vis == nullptr) != (out8 == nullptr)) return fail(c, SV_ERR_INVALID_ARG, "vis and vis_wls must both be given or both be NULL");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    return wls_dev(c, n_frames, d16, vis, guide, out16, out8);
+}
+
+int sv_filter_wls_host(sv_ctx* c, const int16_t* d16, size_t ds, const uint8_t* vis, size_t vs, const uint8_t* guide, size_t gs,
+                       int16_t* out16, size_t os16, uint8_t* out8, size_t os8) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !out16) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if ((vis == nullptr) != (out8 == nullptr)) return fail(c, SV_ERR_INVALID_ARG, "vis and vis_wls must both be given or both be NULL");
+    const size_t W = c->W, H = c->H;
+    if (ds < 2 * W || os16 < 2 * W || (vis && (vs < W || os8 < W)) || (guide && gs < 3 * W))
+        return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    if (!guide && !c->rect_l.p) return fail(c, SV_ERR_INVALID_ARG, "no guide image: pass one or call sv_compute_rgb_host first");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    int rc;
+    if ((rc = ensure(c, c->d16tmp, W * H * 2))) return rc;
+    if ((rc = ensure(c, c->wls_o16, W * H * 2))) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(c->d16tmp.p, 2 * W, d16, ds, 2 * W, H, hipMemcpyHostToDevice, c->stream));
+    if (vis) {
+        if ((rc = ensure(c, c->wls_v, W * H))) return rc;
+        if ((rc = ensure(c, c->wls_o8, W * H))) return rc;
+        HIPCHK(c, hipMemcpy2DAsync(c->wls_v.p, W, vis, vs, W, H, hipMemcpyHostToDevice, c->stream));
+    }
+    const uint8_t* gdev = (const uint8_t*)c->rect_l.p;
+    if (guide) {
+        if ((rc = ensure(c, c->wls_g, W * H * 3))) return rc;
+        HIPCHK(c, hipMemcpy2DAsync(c->wls_g.p, 3 * W, guide, gs, 3 * W, H, hipMemcpyHostToDevice, c->stream));
+        gdev = (const uint8_t*)c->wls_g.p;
+    }
+    if ((rc = wls_dev(c, 1, (const int16_t*)c->d16tmp.p, vis ? (const uint8_t*)c->wls_v.p : nullptr, gdev, (int16_t*)c->wls_o16.p,
+                      vis ? (uint8_t*)c->wls_o8.p : nullptr)))
+        return rc;
+    HIPCHK(c, hipMemcpy2DAsync(out16, os16, c->wls_o16.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    if (vis) HIPCHK(c, hipMemcpy2DAsync(out8, os8, c->wls_o8.p, W, W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }

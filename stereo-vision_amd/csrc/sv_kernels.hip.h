@@ -750,4 +750,157 @@ __global__ __launch_bounds__(256) void k_depth(const int16_t* __restrict__ d16, 
     depth[o] = out;
 }
 
+// ---------------------------------------------------------------------------------------------
+// WLS post-filter.  Result of wls_filter->filter(...) as StereoMatcherNew::filterWLS calls it
+// (StereoMatcher.cpp:154-160) on a filter made by createDisparityWLSFilterGeneric(false) (:265):
+// outside the ROI of computeROI2 (:12-29) the output is 16*(min_disp-1) = -16, inside it is the
+// fast global smoother (3 iterations, lambda x0.25 per iteration) of the disparity guided by the
+// rectified left RGB image.  Each iteration is one tridiagonal (Thomas) solve per row and one per
+// column.  The solves keep the sequential float operation order of the CPU statement, so results
+// match it bit for bit; parallelism comes from rows x images (disp16 and its 8-bit
+// visualisation are filtered together, frames of a batch too).
+//   cur / tmp : [n_img][rh][rw] float   (n_img = n_frames * K, image i uses the weights of frame i / K)
+//   wh / wv   : [n_frames][rh][rw] float, negative edge weights, 0 on the last column / row
+// ---------------------------------------------------------------------------------------------
+constexpr int WLS_LUT_SIZE = 3 * 256 * 256;
+
+__global__ __launch_bounds__(256) void k_wls_weights(const uint8_t* __restrict__ guide, const float* __restrict__ lut,
+                                                      float* __restrict__ wh, float* __restrict__ wv, int W, int H, int rx,
+                                                      int ry, int rw, int rh) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, f = blockIdx.z;
+    if (j >= rw) return;
+    const uint8_t* p = guide + ((size_t)f * H * W + (size_t)(ry + i) * W + rx + j) * 3;
+    const int a0 = p[0], a1 = p[1], a2 = p[2];
+    float h = 0.0f, v = 0.0f;
+    if (j < rw - 1) {
+        const int d0 = a0 - p[3], d1 = a1 - p[4], d2 = a2 - p[5];
+        h = lut[d0 * d0 + d1 * d1 + d2 * d2];
+    }
+    if (i < rh - 1) {
+        const uint8_t* q = p + (size_t)W * 3;
+        const int d0 = a0 - q[0], d1 = a1 - q[1], d2 = a2 - q[2];
+        v = lut[d0 * d0 + d1 * d1 + d2 * d2];
+    }
+    const size_t o = ((size_t)f * rh + i) * rw + j;
+    wh[o] = h;
+    wv[o] = v;
+}
+
+// disparity16 (k = 0) and the 8-bit visualisation (k = 1, when K == 2) of the ROI -> float
+__global__ __launch_bounds__(256) void k_wls_load(const int16_t* __restrict__ d16, const uint8_t* __restrict__ vis,
+                                                   float* __restrict__ cur, int W, int H, int rx, int ry, int rw, int rh, int K) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, img = blockIdx.z;
+    if (j >= rw) return;
+    const int f = img / K, k = img - f * K;
+    const size_t src = (size_t)f * H * W + (size_t)(ry + i) * W + rx + j;
+    cur[((size_t)img * rh + i) * rw + j] = k == 0 ? (float)d16[src] : (float)vis[src];
+}
+
+// float -> int16 / u8 with saturate_cast(cvRound(.)), -16 outside the ROI (0 after the u8 saturation)
+__global__ __launch_bounds__(256) void k_wls_store(const float* __restrict__ cur, int16_t* __restrict__ out16,
+                                                    uint8_t* __restrict__ out8, int W, int H, int rx, int ry, int rw, int rh,
+                                                    int K) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+    if (x >= W) return;
+    const int f = img / K, k = img - f * K;
+    const bool in = x >= rx && x < rx + rw && y >= ry && y < ry + rh;
+    const float v = in ? cur[((size_t)img * rh + (y - ry)) * rw + (x - rx)] : -16.0f;
+    const float r = rintf(v);  // round half to even
+    const size_t o = (size_t)f * H * W + (size_t)y * W + x;
+    if (k == 0) out16[o] = (int16_t)fminf(fmaxf(r, -32768.0f), 32767.0f);
+    else out8[o] = (uint8_t)fminf(fmaxf(r, 0.0f), 255.0f);
+}
+
+// Row solves.  One wave owns 64 rows; the row is walked in 64-column chunks that are moved
+// between HBM/L2 and LDS with coalesced accesses and read by the solving lane along its own LDS
+// row (stride 65 words: conflict-free).  The forward sweep leaves the modified right-hand side in
+// cur and the modified super-diagonal in tmp; the backward sweep walks the chunks in reverse.
+constexpr int FGS_T = 64;
+__global__ __launch_bounds__(64) void k_fgs_hpass(float* __restrict__ cur, const float* __restrict__ wh, float* __restrict__ tmp,
+                                                   int rw, int rh, int K, float lambda) {
+    __shared__ float t_c[FGS_T][FGS_T + 1], t_w[FGS_T][FGS_T + 1], t_t[FGS_T][FGS_T + 1];
+    const int img = blockIdx.y, f = img / K, lane = threadIdx.x;
+    const int r0 = blockIdx.x * FGS_T, nrows = min(FGS_T, rh - r0);
+    float* curI = cur + ((size_t)img * rh + r0) * rw;
+    float* tmpI = tmp + ((size_t)img * rh + r0) * rw;
+    const float* whI = wh + ((size_t)f * rh + r0) * rw;
+    const bool rowok = lane < nrows;
+    float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
+    const int nchunks = (rw + FGS_T - 1) / FGS_T;
+    for (int c = 0; c < nchunks; c++) {
+        const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
+        if (lane < nc)
+            for (int r = 0; r < nrows; r++) {
+                t_c[r][lane] = curI[(size_t)r * rw + c0 + lane];
+                t_w[r][lane] = whI[(size_t)r * rw + c0 + lane];
+            }
+        __syncthreads();
+        if (rowok)
+            for (int j = 0; j < nc; j++) {
+                const float coef_cur = lambda * t_w[lane][j];
+                const float denom = (1.0f - coef_prev - coef_cur) - coef_prev * prev_tmp;
+                prev_tmp = coef_cur / denom;
+                prev_cur = (t_c[lane][j] - coef_prev * prev_cur) / denom;
+                t_t[lane][j] = prev_tmp;
+                t_c[lane][j] = prev_cur;
+                coef_prev = coef_cur;
+            }
+        __syncthreads();
+        if (lane < nc)
+            for (int r = 0; r < nrows; r++) {
+                curI[(size_t)r * rw + c0 + lane] = t_c[r][lane];
+                tmpI[(size_t)r * rw + c0 + lane] = t_t[r][lane];
+            }
+        __syncthreads();
+    }
+    float next = 0.0f;
+    for (int c = nchunks - 1; c >= 0; c--) {
+        const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
+        if (lane < nc)
+            for (int r = 0; r < nrows; r++) {
+                t_c[r][lane] = curI[(size_t)r * rw + c0 + lane];
+                t_t[r][lane] = tmpI[(size_t)r * rw + c0 + lane];
+            }
+        __syncthreads();
+        if (rowok)
+            for (int j = nc - 1; j >= 0; j--) {
+                // the last sample of the row is final after the forward sweep
+                const float v = (c0 + j == rw - 1) ? t_c[lane][j] : t_c[lane][j] - t_t[lane][j] * next;
+                t_c[lane][j] = v;
+                next = v;
+            }
+        __syncthreads();
+        if (lane < nc)
+            for (int r = 0; r < nrows; r++) curI[(size_t)r * rw + c0 + lane] = t_c[r][lane];
+        __syncthreads();
+    }
+}
+
+// Column solves: one lane per column, rows walked in order (coalesced across the wave).
+__global__ __launch_bounds__(64) void k_fgs_vpass(float* __restrict__ cur, const float* __restrict__ wv, float* __restrict__ tmp,
+                                                   int rw, int rh, int K, float lambda) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, img = blockIdx.y, f = img / K;
+    if (j >= rw) return;
+    float* curI = cur + (size_t)img * rh * rw + j;
+    float* tmpI = tmp + (size_t)img * rh * rw + j;
+    const float* wvI = wv + (size_t)f * rh * rw + j;
+    float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < rh; i++) {
+        const float coef_cur = lambda * wvI[(size_t)i * rw];
+        const float denom = (1.0f - coef_prev - coef_cur) - coef_prev * prev_tmp;
+        prev_tmp = coef_cur / denom;
+        prev_cur = (curI[(size_t)i * rw] - coef_prev * prev_cur) / denom;
+        tmpI[(size_t)i * rw] = prev_tmp;
+        curI[(size_t)i * rw] = prev_cur;
+        coef_prev = coef_cur;
+    }
+    float next = prev_cur;
+#pragma unroll 4
+    for (int i = rh - 2; i >= 0; i--) {
+        next = curI[(size_t)i * rw] - tmpI[(size_t)i * rw] * next;
+        curI[(size_t)i * rw] = next;
+    }
+}
+
 }  // namespace svk

@@ -29,6 +29,7 @@ EXPORTS = (
     "sv_compute_gray_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
+    "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
     "sv_algorithmic_bytes", "sv_last_error", "sv_version")
 
@@ -96,6 +97,9 @@ def load():
     L.sv_filter_speckles_dev.argtypes = [vp, vp, i32, i32]
     L.sv_depth_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz]
     L.sv_depth_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.sv_wls_roi.argtypes = [vp, C.POINTER(C.c_int * 4)]
+    L.sv_filter_wls_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.sv_filter_wls_host.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz]
     L.sv_set_debug.argtypes = [vp, i32]
     L.sv_debug_read_volume_host.argtypes = [vp, i32, vp, sz]
     L.sv_debug_read_plane_host.argtypes = [vp, i32, vp]
@@ -215,6 +219,30 @@ class Matcher:
         self._chk(self._L.sv_depth_host(self._h, _ptr(d), 2 * self.W, _ptr(mapper), _ptr(Q), _ptr(R), _ptr(out),
                                         4 * self.W))
         return out
+
+    def wls_roi(self):
+        r = (C.c_int * 4)()
+        self._chk(self._L.sv_wls_roi(self._h, C.byref(r)))
+        return tuple(r)
+
+    def filter_wls(self, disp16, guide_rgb=None, vis=None):
+        """filterWLS on host arrays; guide_rgb None = rectified left image of the last compute_rgb."""
+        d = np.ascontiguousarray(disp16, np.int16)
+        out16 = np.empty((self.H, self.W), np.int16)
+        g = np.ascontiguousarray(guide_rgb, np.uint8) if guide_rgb is not None else None
+        v = np.ascontiguousarray(vis, np.uint8) if vis is not None else None
+        out8 = np.empty((self.H, self.W), np.uint8) if vis is not None else None
+        self._chk(self._L.sv_filter_wls_host(
+            self._h, _ptr(d), 2 * self.W, _ptr(v) if v is not None else None, self.W,
+            _ptr(g) if g is not None else None, 3 * self.W, _ptr(out16), 2 * self.W,
+            _ptr(out8) if out8 is not None else None, self.W))
+        return (out16, out8) if vis is not None else out16
+
+    def filter_wls_dev(self, n, disp_t, guide_t, out_t, vis_t=None, vis_out_t=None):
+        self._chk(self._L.sv_filter_wls_dev(
+            self._h, n, C.c_void_p(disp_t.data_ptr()), C.c_void_p(vis_t.data_ptr()) if vis_t is not None else None,
+            C.c_void_p(guide_t.data_ptr()), C.c_void_p(out_t.data_ptr()),
+            C.c_void_p(vis_out_t.data_ptr()) if vis_out_t is not None else None))
 
     def set_debug(self, on=True):
         self._chk(self._L.sv_set_debug(self._h, int(on)))
