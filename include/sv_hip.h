@@ -216,10 +216,13 @@ int sv_depth_dev(sv_ctx* ctx, const int16_t* disp16_dev, const float* mapper_dev
 /* Stage access for parity tests and profiling (no counterpart in the
  * reference beyond the #if 0 dump blocks, bova_sgm.cu:141-321).  Copies the
  * internal [H][W-D][D] int16 volumes of the LAST sv_compute_* call to host.
- * which: 0 = C (matching cost + P2), 1 = S (aggregated).  S only exists in
- * debug mode (sv_set_debug(ctx, 1)): normally the last path keeps the finished
- * S in registers, runs WTA there and never stores it.                         */
-int sv_set_debug(sv_ctx* ctx, int enable);
+ * which: 0 = C (matching cost + P2), 1 = S (aggregated).  S is only complete in
+ * debug mode.  sv_set_debug modes: 0 = production (batches of >= 6 frames fuse
+ * WTA into the last path, which then keeps the finished S in registers and
+ * never stores it; smaller batches, being latency-bound, run WTA as its own
+ * kernel), 1 = debug (S always materialised), 2 = WTA fused whatever the batch
+ * size (so that tests can exercise the fused kernels on one frame).           */
+int sv_set_debug(sv_ctx* ctx, int mode);
 int sv_debug_read_volume_host(sv_ctx* ctx, int which, int16_t* vol_host, size_t n_elems);
 /* which: 0 = disp before LR check, 1 = raw integer disparity, 2 = minS,
  * 3 = disp after LR check (before median).  width*height int16.               */

@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -40,6 +41,8 @@ struct sv_ctx {
     Buf C, S;                // u16 [H][W1][D]
     Buf rec;                 // WTA records {disp16, raw, minS, 0} [H][W] x 8 bytes
     bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
+    bool force_fuse = false; // sv_set_debug(ctx, 2): WTA fused into the last path whatever the batch size
+    int fuse_wta_min_batch = 6;  // batches below this run WTA as its own kernel (see run_sgm; crossover measured at 640x480 D=128)
     Buf disp_lr, out;        // i16 [H][W]
     Buf rgb_l, rgb_r;        // u8 [H][W][3] input staging
     Buf rect_l, rect_r;      // u8 [H][W][3] rectified
@@ -133,6 +136,14 @@ int alloc_core(sv_ctx* c) {
     if ((rc = ensure(c, c->disp_lr, npx * 2))) return rc;
     if ((rc = ensure(c, c->out, npx * 2))) return rc;
     return SV_OK;
+}
+
+// Strided host<->device image copy.  Dense rows (the usual case: cv::Mat::isContinuous) go through
+// one linear copy: hipMemcpy2DAsync on pageable host memory costs milliseconds per 640x480 image.
+hipError_t copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind,
+                  hipStream_t stream) {
+    if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * height, kind, stream);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, stream);
 }
 
 struct DevGuard {
@@ -261,7 +272,7 @@ int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff, int nb) {
     int* cnt = (int*)c->cnt.p;
     hipLaunchKernelGGL(svk::k_speckle_init, g1, b, 0, c->stream, img, lab, cnt, n);
     hipLaunchKernelGGL(svk::k_speckle_merge, g2, b, 0, c->stream, img, lab, c->W, c->H, SV_INVALID_DISP_SCALED, max_diff);
-    hipLaunchKernelGGL(svk::k_speckle_count, g1, b, 0, c->stream, img, lab, cnt, n, SV_INVALID_DISP_SCALED);
+    hipLaunchKernelGGL(svk::k_speckle_count, dim3((n + 1023) / 1024), dim3(1024), 0, c->stream, img, lab, cnt, n, SV_INVALID_DISP_SCALED);
     hipLaunchKernelGGL(svk::k_speckle_apply, g1, b, 0, c->stream, img, lab, cnt, n, SV_INVALID_DISP_SCALED, max_size);
     HIPCHK(c, hipGetLastError());
     return SV_OK;
@@ -331,6 +342,10 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     int e = 0;
     hipEvent_t* evs = c->ev[c->ev_calls % sv_ctx::EV_RING];
     auto mark = [&]() { if (tm) (void)hipEventRecord(evs[e++], c->stream); };
+    // Fusing WTA into the last path saves one volume write + read but triples that launch's
+    // instruction count per step; with few frames in flight the path kernels are latency-bound
+    // (one wave per SIMD or less), so the fusion only pays once the batch fills the chip.
+    const bool fuse = !c->debug && (c->force_fuse || nb >= c->fuse_wta_min_batch);
     mark();
     // 1. prefilter + BT statistics
     hipLaunchKernelGGL(svk::k_stats, dim3((W + 255) / 256, H, 2 * nb), dim3(256), 0, c->stream, left, right, (uint2*)c->stat_l.p,
@@ -350,13 +365,13 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         bool first = true;
         for (int dir = 0; dir < 8; dir++)
             if (p.path_mask & (1u << dir)) {
-                launch_agg(c, dir, (first ? 1 : 0) | ((dir == last && !c->debug) ? 2 : 0), nb);
+                launch_agg(c, dir, (first ? 1 : 0) | ((dir == last && fuse) ? 2 : 0), nb);
                 first = false;
             }
     }
     mark();
-    // 4. WTA (its own kernel only in debug mode)
-    if (c->debug) launch_wta(c, nb);
+    // 4. WTA as its own kernel when it was not fused into the last path
+    if (!fuse) launch_wta(c, nb);
     mark();
     // 5. LR check, median, speckle
     {
@@ -436,6 +451,7 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     for (int r = 0; r < sv_ctx::EV_RING; r++)
         for (int i = 0; i < sv_ctx::EV_PER; i++) HIPCHK(c, hipEventCreate(&c->ev[r][i]));
     c->ev_ok = true;
+    if (const char* e = getenv("SV_FUSE_WTA_MIN_BATCH")) c->fuse_wta_min_batch = atoi(e);  // tuning knob
     return alloc_core(c);
 }
 
@@ -524,10 +540,10 @@ int sv_compute_gray_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_
     int rc;
     if ((rc = ensure(c, c->img_l, W * H))) return rc;
     if ((rc = ensure(c, c->img_r, W * H))) return rc;
-    HIPCHK(c, hipMemcpy2DAsync(c->img_l.p, W, left, ls, W, H, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(c->img_r.p, W, right, rs, W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, copy2d(c->img_l.p, W, left, ls, W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, copy2d(c->img_r.p, W, right, rs, W, H, hipMemcpyHostToDevice, c->stream));
     if ((rc = run_sgm(c, (const uint8_t*)c->img_l.p, (const uint8_t*)c->img_r.p, (int16_t*)c->out.p))) return rc;
-    HIPCHK(c, hipMemcpy2DAsync(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy2d(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }
@@ -586,8 +602,8 @@ int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t
     if ((rc = ensure(c, c->gray_r, W * H))) return rc;
     Buf& dl = rectify ? c->rgb_l : c->rect_l;
     Buf& dr = rectify ? c->rgb_r : c->rect_r;
-    HIPCHK(c, hipMemcpy2DAsync(dl.p, 3 * W, left, ls, 3 * W, H, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(dr.p, 3 * W, right, rs, 3 * W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, copy2d(dl.p, 3 * W, left, ls, 3 * W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, copy2d(dr.p, 3 * W, right, rs, 3 * W, H, hipMemcpyHostToDevice, c->stream));
     if (rectify) {
         if ((rc = sv_remap_rgb_dev(c, 0, (const uint8_t*)c->rgb_l.p, (uint8_t*)c->rect_l.p))) return rc;
         if ((rc = sv_remap_rgb_dev(c, 1, (const uint8_t*)c->rgb_r.p, (uint8_t*)c->rect_r.p))) return rc;
@@ -595,7 +611,7 @@ int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t
     if ((rc = sv_gray_from_rgb_dev(c, (const uint8_t*)c->rect_l.p, (uint8_t*)c->gray_l.p))) return rc;
     if ((rc = sv_gray_from_rgb_dev(c, (const uint8_t*)c->rect_r.p, (uint8_t*)c->gray_r.p))) return rc;
     if ((rc = run_sgm(c, (const uint8_t*)c->gray_l.p, (const uint8_t*)c->gray_r.p, (int16_t*)c->out.p))) return rc;
-    HIPCHK(c, hipMemcpy2DAsync(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy2d(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }
@@ -607,7 +623,7 @@ int sv_get_rectified_host(sv_ctx* c, int which, uint8_t* rgb, size_t stride) {
     if (!rgb || stride < 3 * W || which < 0 || which > 1) return fail(c, SV_ERR_INVALID_ARG, "bad argument");
     if (!b.p) return fail(c, SV_ERR_INVALID_ARG, "no rectified image yet (call sv_compute_rgb_host first)");
     DevGuard g(c->device);
-    HIPCHK(c, hipMemcpy2DAsync(rgb, stride, b.p, 3 * W, 3 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy2d(rgb, stride, b.p, 3 * W, 3 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }
@@ -669,10 +685,10 @@ int sv_depth_host(sv_ctx* c, const int16_t* d16, size_t dstride, const float* ma
     if ((rc = ensure(c, c->d16tmp, W * H * 2))) return rc;
     if ((rc = ensure(c, c->mapper, W * H * 8))) return rc;
     if ((rc = ensure(c, c->depth, W * H * 4))) return rc;
-    HIPCHK(c, hipMemcpy2DAsync(c->d16tmp.p, 2 * W, d16, dstride, 2 * W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, copy2d(c->d16tmp.p, 2 * W, d16, dstride, 2 * W, H, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->mapper.p, mapper, W * H * 8, hipMemcpyHostToDevice, c->stream));
     if ((rc = sv_depth_dev(c, (const int16_t*)c->d16tmp.p, (const float*)c->mapper.p, Q, R, (float*)c->depth.p))) return rc;
-    HIPCHK(c, hipMemcpy2DAsync(depth, ostride, c->depth.p, 4 * W, 4 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy2d(depth, ostride, c->depth.p, 4 * W, 4 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }
@@ -707,30 +723,31 @@ int sv_filter_wls_host(sv_ctx* c, const int16_t* d16, size_t ds, const uint8_t* 
     int rc;
     if ((rc = ensure(c, c->d16tmp, W * H * 2))) return rc;
     if ((rc = ensure(c, c->wls_o16, W * H * 2))) return rc;
-    HIPCHK(c, hipMemcpy2DAsync(c->d16tmp.p, 2 * W, d16, ds, 2 * W, H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, copy2d(c->d16tmp.p, 2 * W, d16, ds, 2 * W, H, hipMemcpyHostToDevice, c->stream));
     if (vis) {
         if ((rc = ensure(c, c->wls_v, W * H))) return rc;
         if ((rc = ensure(c, c->wls_o8, W * H))) return rc;
-        HIPCHK(c, hipMemcpy2DAsync(c->wls_v.p, W, vis, vs, W, H, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, copy2d(c->wls_v.p, W, vis, vs, W, H, hipMemcpyHostToDevice, c->stream));
     }
     const uint8_t* gdev = (const uint8_t*)c->rect_l.p;
     if (guide) {
         if ((rc = ensure(c, c->wls_g, W * H * 3))) return rc;
-        HIPCHK(c, hipMemcpy2DAsync(c->wls_g.p, 3 * W, guide, gs, 3 * W, H, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, copy2d(c->wls_g.p, 3 * W, guide, gs, 3 * W, H, hipMemcpyHostToDevice, c->stream));
         gdev = (const uint8_t*)c->wls_g.p;
     }
     if ((rc = wls_dev(c, 1, (const int16_t*)c->d16tmp.p, vis ? (const uint8_t*)c->wls_v.p : nullptr, gdev, (int16_t*)c->wls_o16.p,
                       vis ? (uint8_t*)c->wls_o8.p : nullptr)))
         return rc;
-    HIPCHK(c, hipMemcpy2DAsync(out16, os16, c->wls_o16.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
-    if (vis) HIPCHK(c, hipMemcpy2DAsync(out8, os8, c->wls_o8.p, W, W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy2d(out16, os16, c->wls_o16.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    if (vis) HIPCHK(c, copy2d(out8, os8, c->wls_o8.p, W, W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }
 
 int sv_set_debug(sv_ctx* c, int enable) {
     if (!c) return SV_ERR_INVALID_ARG;
-    c->debug = enable != 0;
+    c->debug = enable == 1;
+    c->force_fuse = enable == 2;
     return SV_OK;
 }
 

@@ -672,13 +672,46 @@ __global__ __launch_bounds__(256) void k_speckle_merge(const int16_t* __restrict
     if (x + 1 < W) { int u = img[i + 1]; if (u != new_val && abs(u - v) <= max_diff) uf_union(lab, i, i + 1); }
     if (y + 1 < H) { int u = img[i + W]; if (u != new_val && abs(u - v) <= max_diff) uf_union(lab, i, i + W); }
 }
-__global__ __launch_bounds__(256) void k_speckle_count(const int16_t* __restrict__ img, int* __restrict__ lab,
-                                                        int* __restrict__ cnt, int n, int new_val) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || img[i] == new_val) return;
-    int r = uf_find(lab, i);
-    lab[i] = r;  // path compression: only ever lowers a label towards its root
-    atomicAdd(&cnt[r], 1);
+// Component sizes.  A large component would otherwise take one global atomic per pixel on a single
+// address (measured 2.4 ms per 640x480 frame); pixels of a wave mostly share a root, so each wave
+// first groups its lanes by root (readfirstlane / ballot loop) and the block then merges the wave
+// totals of equal roots in LDS, leaving a handful of global atomics per block.
+__global__ __launch_bounds__(1024) void k_speckle_count(const int16_t* __restrict__ img, int* __restrict__ lab,
+                                                         int* __restrict__ cnt, int n, int new_val) {
+    constexpr int MAXE = 128;
+    __shared__ int e_root[MAXE], e_cnt[MAXE], e_n;
+    if (threadIdx.x == 0) e_n = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < n && img[i] != new_val;
+    int r = -1;
+    if (active) {
+        r = uf_find(lab, i);
+        lab[i] = r;  // path compression: only ever lowers a label towards its root
+    }
+    while (__ballot(active)) {
+        const unsigned long long live = __ballot(active);
+        const int leader = __ffsll((long long)live) - 1;
+        const int r0 = __shfl(r, leader);
+        const bool mine = active && r == r0;
+        const unsigned long long same = __ballot(mine);
+        if ((int)(threadIdx.x & 63) == leader) {
+            const int slot = atomicAdd(&e_n, 1);
+            if (slot < MAXE) { e_root[slot] = r0; e_cnt[slot] = __popcll(same); }
+            else atomicAdd(&cnt[r0], __popcll(same));
+        }
+        active = active && !mine;
+    }
+    __syncthreads();
+    const int ne = min(e_n, MAXE), t = threadIdx.x;
+    int first = t;
+    if (t < ne)
+        for (int j = 0; j < t; j++)
+            if (e_root[j] == e_root[t]) { first = j; break; }
+    __syncthreads();
+    if (t < ne && first != t) atomicAdd(&e_cnt[first], e_cnt[t]);
+    __syncthreads();
+    if (t < ne && first == t) atomicAdd(&cnt[e_root[t]], e_cnt[t]);
 }
 __global__ __launch_bounds__(256) void k_speckle_apply(int16_t* __restrict__ img, const int* __restrict__ lab,
                                                         const int* __restrict__ cnt, int n, int new_val, int max_size) {
@@ -815,7 +848,39 @@ __global__ __launch_bounds__(256) void k_wls_store(const float* __restrict__ cur
 // between HBM/L2 and LDS with coalesced accesses and read by the solving lane along its own LDS
 // row (stride 65 words: conflict-free).  The forward sweep leaves the modified right-hand side in
 // cur and the modified super-diagonal in tmp; the backward sweep walks the chunks in reverse.
-constexpr int FGS_T = 64;
+// The solve itself is a serial dependency chain (mul, sub, div per sample), so inside a chunk the
+// lane moves FGS_R samples at a time between LDS and registers: the LDS round trips then overlap
+// the chain instead of sitting on it.
+constexpr int FGS_T = 64, FGS_R = 16;
+__device__ __forceinline__ void fgs_step(float w, float& c, float& t, float lambda, float& coef_prev, float& prev_cur,
+                                         float& prev_tmp) {
+    const float coef_cur = lambda * w;
+    const float denom = (1.0f - coef_prev - coef_cur) - coef_prev * prev_tmp;
+    prev_tmp = coef_cur / denom;
+    prev_cur = (c - coef_prev * prev_cur) / denom;
+    t = prev_tmp;
+    c = prev_cur;
+    coef_prev = coef_cur;
+}
+// 64x64 tile <-> global, one row per wave-load (256 contiguous bytes), 8 rows in flight.  Rows past
+// nrows re-read the last valid row (never written back); columns past nc are skipped.
+__device__ __forceinline__ void fgs_tile_load(float (*t)[FGS_T + 1], const float* __restrict__ g, int rw, int nrows, int col,
+                                              bool colok, int lane) {
+    if (!colok) return;
+#pragma unroll 1
+    for (int r = 0; r < FGS_T; r += 8) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = g[(size_t)min(r + u, nrows - 1) * rw + col];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[r + u][lane] = a[u];
+    }
+}
+__device__ __forceinline__ void fgs_tile_store(const float (*t)[FGS_T + 1], float* __restrict__ g, int rw, int nrows, int col,
+                                               bool colok, int lane) {
+    if (!colok) return;
+    for (int r = 0; r < nrows; r++) g[(size_t)r * rw + col] = t[r][lane];
+}
 __global__ __launch_bounds__(64) void k_fgs_hpass(float* __restrict__ cur, const float* __restrict__ wh, float* __restrict__ tmp,
                                                    int rw, int rh, int K, float lambda) {
     __shared__ float t_c[FGS_T][FGS_T + 1], t_w[FGS_T][FGS_T + 1], t_t[FGS_T][FGS_T + 1];
@@ -824,82 +889,122 @@ __global__ __launch_bounds__(64) void k_fgs_hpass(float* __restrict__ cur, const
     float* curI = cur + ((size_t)img * rh + r0) * rw;
     float* tmpI = tmp + ((size_t)img * rh + r0) * rw;
     const float* whI = wh + ((size_t)f * rh + r0) * rw;
-    const bool rowok = lane < nrows;
     float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
     const int nchunks = (rw + FGS_T - 1) / FGS_T;
     for (int c = 0; c < nchunks; c++) {
         const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
-        if (lane < nc)
-            for (int r = 0; r < nrows; r++) {
-                t_c[r][lane] = curI[(size_t)r * rw + c0 + lane];
-                t_w[r][lane] = whI[(size_t)r * rw + c0 + lane];
-            }
+        fgs_tile_load(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
+        fgs_tile_load(t_w, whI, rw, nrows, c0 + lane, lane < nc, lane);
         __syncthreads();
-        if (rowok)
-            for (int j = 0; j < nc; j++) {
-                const float coef_cur = lambda * t_w[lane][j];
-                const float denom = (1.0f - coef_prev - coef_cur) - coef_prev * prev_tmp;
-                prev_tmp = coef_cur / denom;
-                prev_cur = (t_c[lane][j] - coef_prev * prev_cur) / denom;
-                t_t[lane][j] = prev_tmp;
-                t_c[lane][j] = prev_cur;
-                coef_prev = coef_cur;
+        // rows past nrows solve garbage that is never written back
+        for (int j0 = 0; j0 < nc; j0 += FGS_R) {
+            float cc[FGS_R], ww[FGS_R], tt[FGS_R];
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) { cc[u] = t_c[lane][j0 + u]; ww[u] = t_w[lane][j0 + u]; }
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) {
+                tt[u] = 0.0f;
+                if (j0 + u < nc) fgs_step(ww[u], cc[u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
             }
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) { t_c[lane][j0 + u] = cc[u]; t_t[lane][j0 + u] = tt[u]; }
+        }
         __syncthreads();
-        if (lane < nc)
-            for (int r = 0; r < nrows; r++) {
-                curI[(size_t)r * rw + c0 + lane] = t_c[r][lane];
-                tmpI[(size_t)r * rw + c0 + lane] = t_t[r][lane];
-            }
+        fgs_tile_store(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
+        fgs_tile_store(t_t, tmpI, rw, nrows, c0 + lane, lane < nc, lane);
         __syncthreads();
     }
     float next = 0.0f;
     for (int c = nchunks - 1; c >= 0; c--) {
         const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
-        if (lane < nc)
-            for (int r = 0; r < nrows; r++) {
-                t_c[r][lane] = curI[(size_t)r * rw + c0 + lane];
-                t_t[r][lane] = tmpI[(size_t)r * rw + c0 + lane];
-            }
+        fgs_tile_load(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
+        fgs_tile_load(t_t, tmpI, rw, nrows, c0 + lane, lane < nc, lane);
         __syncthreads();
-        if (rowok)
-            for (int j = nc - 1; j >= 0; j--) {
-                // the last sample of the row is final after the forward sweep
-                const float v = (c0 + j == rw - 1) ? t_c[lane][j] : t_c[lane][j] - t_t[lane][j] * next;
-                t_c[lane][j] = v;
-                next = v;
+        for (int j0 = FGS_T - FGS_R; j0 >= 0; j0 -= FGS_R) {
+            float cc[FGS_R], tt[FGS_R];
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) { cc[u] = t_c[lane][j0 + u]; tt[u] = t_t[lane][j0 + u]; }
+#pragma unroll
+            for (int u = FGS_R - 1; u >= 0; u--) {
+                const int j = j0 + u;
+                if (j < nc) {
+                    // the last sample of the row is final after the forward sweep
+                    next = (c0 + j == rw - 1) ? cc[u] : cc[u] - tt[u] * next;
+                    cc[u] = next;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) t_c[lane][j0 + u] = cc[u];
+        }
         __syncthreads();
-        if (lane < nc)
-            for (int r = 0; r < nrows; r++) curI[(size_t)r * rw + c0 + lane] = t_c[r][lane];
+        fgs_tile_store(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
         __syncthreads();
     }
 }
 
-// Column solves: one lane per column, rows walked in order (coalesced across the wave).
+// Column solves: one lane per column, rows walked in order (coalesced across the wave), FGS_V rows
+// per trip with the next trip's loads issued before the current chain is computed.
+constexpr int FGS_V = 8;
 __global__ __launch_bounds__(64) void k_fgs_vpass(float* __restrict__ cur, const float* __restrict__ wv, float* __restrict__ tmp,
                                                    int rw, int rh, int K, float lambda) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, img = blockIdx.y, f = img / K;
-    if (j >= rw) return;
+    const int j = min((int)(blockIdx.x * blockDim.x + threadIdx.x), rw - 1);  // surplus lanes repeat the last column
+    const int img = blockIdx.y, f = img / K;
     float* curI = cur + (size_t)img * rh * rw + j;
     float* tmpI = tmp + (size_t)img * rh * rw + j;
     const float* wvI = wv + (size_t)f * rh * rw + j;
     float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
-#pragma unroll 4
-    for (int i = 0; i < rh; i++) {
-        const float coef_cur = lambda * wvI[(size_t)i * rw];
-        const float denom = (1.0f - coef_prev - coef_cur) - coef_prev * prev_tmp;
-        prev_tmp = coef_cur / denom;
-        prev_cur = (curI[(size_t)i * rw] - coef_prev * prev_cur) / denom;
-        tmpI[(size_t)i * rw] = prev_tmp;
-        curI[(size_t)i * rw] = prev_cur;
-        coef_prev = coef_cur;
+    float cn[FGS_V], wn[FGS_V];
+#pragma unroll
+    for (int u = 0; u < FGS_V; u++) {
+        const size_t o = (size_t)min(u, rh - 1) * rw;
+        cn[u] = curI[o];
+        wn[u] = wvI[o];
     }
+    for (int i0 = 0; i0 < rh; i0 += FGS_V) {
+        float cc[FGS_V], ww[FGS_V], tt[FGS_V];
+#pragma unroll
+        for (int u = 0; u < FGS_V; u++) { cc[u] = cn[u]; ww[u] = wn[u]; }
+#pragma unroll
+        for (int u = 0; u < FGS_V; u++) {
+            const size_t o = (size_t)min(i0 + FGS_V + u, rh - 1) * rw;
+            cn[u] = curI[o];
+            wn[u] = wvI[o];
+        }
+#pragma unroll
+        for (int u = 0; u < FGS_V; u++)
+            if (i0 + u < rh) {
+                fgs_step(ww[u], cc[u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
+                tmpI[(size_t)(i0 + u) * rw] = tt[u];
+                curI[(size_t)(i0 + u) * rw] = cc[u];
+            }
+    }
+    // backward: rows rh-2 .. 0 (row rh-1 is final); trips aligned to the same FGS_V grid
     float next = prev_cur;
-#pragma unroll 4
-    for (int i = rh - 2; i >= 0; i--) {
-        next = curI[(size_t)i * rw] - tmpI[(size_t)i * rw] * next;
-        curI[(size_t)i * rw] = next;
+    const int ilast = rh - 2;
+    if (ilast < 0) return;
+    int i0 = ilast - ilast % FGS_V;
+#pragma unroll
+    for (int u = 0; u < FGS_V; u++) {
+        const size_t o = (size_t)min(i0 + u, rh - 1) * rw;
+        cn[u] = curI[o];
+        wn[u] = tmpI[o];
+    }
+    for (; i0 >= 0; i0 -= FGS_V) {
+        float cc[FGS_V], tt[FGS_V];
+#pragma unroll
+        for (int u = 0; u < FGS_V; u++) { cc[u] = cn[u]; tt[u] = wn[u]; }
+#pragma unroll
+        for (int u = 0; u < FGS_V; u++) {
+            const size_t o = (size_t)max(i0 - FGS_V + u, 0) * rw;
+            cn[u] = curI[o];
+            wn[u] = tmpI[o];
+        }
+#pragma unroll
+        for (int u = FGS_V - 1; u >= 0; u--)
+            if (i0 + u <= ilast) {
+                next = cc[u] - tt[u] * next;
+                curI[(size_t)(i0 + u) * rw] = next;
+            }
     }
 }
 

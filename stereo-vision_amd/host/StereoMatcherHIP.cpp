@@ -120,10 +120,34 @@ void StereoMatcherNew::filterBLF(std::string kind) {
 }
 
 void StereoMatcherNew::filterWLS(std::string kind) {
-    if (stereo_parameters.WLSfiltering != WLS_DISABLED)
-        std::cout << "[StereoMatcherNew] !! WLS filtering is not part of the sgbm_hip build yet, passing through." << std::endl;
-    disparity_wls = getDisparity(kind).clone();      // StereoMatcher.cpp:193-197
-    disparity16_wls = getDisparity16(kind).clone();
+    Image input = getDisparity(kind);
+    Image input16 = getDisparity16(kind);
+    switch (stereo_parameters.WLSfiltering) {
+        case WLS_ENABLED: {
+            // StereoMatcher.cpp:154-160: lambda / sigma / ROI (computeROI2) are taken from the
+            // parameters pushed by updateHIPParams(); the guide is the rectified left image, which
+            // compute() left on the device (guide pointer NULL).
+            if (!ctx || input16.empty() || input.empty()) break;
+            Image out16(input16.rows, input16.cols, 1, 2), out8(input.rows, input.cols, 1, 1);
+            last_rc = sv_filter_wls_host(ctx, input16.ptr<int16_t>(), input16.step(), input.ptr<uint8_t>(), input.step(), nullptr, 0,
+                                         out16.ptr<int16_t>(), out16.step(), out8.ptr<uint8_t>(), out8.step());
+            if (last_rc != 0) {
+                std::cout << "[StereoMatcherNew] !! sv_filter_wls_host failed: " << sv_last_error(ctx) << std::endl;
+                break;  // pass the input through, as the disabled branch does
+            }
+            disparity_wls = out8;
+            disparity16_wls = out16;
+            return;
+        }
+        case WLS_LRCHECK:
+            // StereoMatcher.cpp:164-186: only defined for SGBM_OPENCV; for every other matcher the
+            // reference clones the input (and, through its missing braces, always clones the 16-bit map)
+        case WLS_DISABLED:
+        default:
+            break;
+    }
+    disparity_wls = input.clone();      // StereoMatcher.cpp:193-197
+    disparity16_wls = input16.clone();
 }
 
 Image StereoMatcherNew::getDisparity(std::string kind) {

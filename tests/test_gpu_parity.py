@@ -35,7 +35,9 @@ def test_stages_bit_exact(gpu, W, H, D, paths, flags, bs, seed):
     ph, po = _params(D, paths, flags=flags, block_size=bs, P1=8 * bs * bs, P2=32 * bs * bs)
     ref, st = svref.sgbm(left, right, po, stages=("C", "S", "disp_wta", "raw", "mins", "disp_lr"))
     m = svhip.Matcher(W, H, ph)
-    fused = m.compute_gray(left, right)  # production path: WTA fused into the last path, S never stored
+    assert np.array_equal(m.compute_gray(left, right), ref), "final disparity16 differs (production path, one frame)"
+    m.set_debug(2)                       # large-batch production path: WTA fused into the last path, S never stored
+    fused = m.compute_gray(left, right)
     assert np.array_equal(fused, ref), "final disparity16 differs (fused WTA)"
     assert np.array_equal(m.debug_plane(2), st["mins"]), "minS differs (fused WTA)"
     assert np.array_equal(m.debug_plane(1), st["raw"]), "raw disparity differs (fused WTA)"
@@ -59,6 +61,8 @@ def test_single_paths(gpu, mask):
     ph, po = _params(D, 8, path_mask=mask, flags=0)
     ref, st = svref.sgbm(left, right, po, stages=("S",))
     m = svhip.Matcher(W, H, ph)
+    assert np.array_equal(m.compute_gray(left, right), ref)
+    m.set_debug(2)
     assert np.array_equal(m.compute_gray(left, right), ref)
     m.set_debug(True)
     got = m.compute_gray(left, right)
