@@ -163,6 +163,30 @@ int sv_gray_from_rgb_dev(sv_ctx* ctx, const uint8_t* rgb_dev, uint8_t* gray_dev)
 int sv_upload_maps_host(sv_ctx* ctx, const float* map_lx, const float* map_ly,
                         const float* map_rx, const float* map_ry);
 
+/* Replaces one cv::initUndistortRectifyMap(K, Dist, Rrect, Prect, size,
+ * CV_32FC1, mapx, mapy) of rectifyImages (stereoCamera.cpp:569-570): the maps
+ * of camera `which` are generated on the device (FP64, OpenCV's row-wise
+ * running sums kept) and used by sv_remap_rgb_dev / sv_compute_rgb_host; no
+ * map crosses PCIe.  The module re-runs this on every frame because the
+ * kinematics mark the camera as changed (DispModule.cpp:684).  K 3x3, R 3x3,
+ * P 3x4 row-major doubles (what cv::stereoRectify returned,
+ * stereoCamera.cpp:564); dist = n_dist <= 8 coefficients k1 k2 p1 p2 k3 k4 k5
+ * k6 (thin-prism / tilt terms are not modelled: SV_ERR_UNSUPPORTED).          */
+int sv_init_rectify_map(sv_ctx* ctx, int which, const double* K, const double* dist, int n_dist,
+                        const double* R, const double* P);
+
+/* Replaces one cv::undistortPoints(grid, grid, K, Dist, Rrect, Prect) of
+ * StereoCamera::updateMappings (stereoCamera.cpp:2437-2472): MapperL (which =
+ * 0) / MapperR (1), CV_32FC2, kept on the device; sv_depth_* use MapperL when
+ * called with a NULL mapper.                                                  */
+int sv_update_mapper(sv_ctx* ctx, int which, const double* K, const double* dist, int n_dist,
+                     const double* R, const double* P);
+
+/* Read-back for callers that need the maps on the host (getMapperL,
+ * stereoCamera.cpp:1915; DispModule::get3DPoints, DispModule.cpp:1103-1197). */
+int sv_get_maps_host(sv_ctx* ctx, int which, float* mapx_host, float* mapy_host);
+int sv_get_mapper_host(sv_ctx* ctx, int which, float* mapper_host);
+
 /* Replaces one cv::remap(.., INTER_LINEAR) (BORDER_CONSTANT 0) of
  * rectifyImages (stereoCamera.cpp:573-574) on an 8UC3 image.  which = 0 left,
  * 1 right.  src/dst are device pointers, 3 bytes/pixel, dense.                */
@@ -206,7 +230,8 @@ int sv_filter_wls_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stri
 
 /* Replaces DispModule::depthFromDisparity (DispModule.cpp:320-366), with the
  * non-aliased read.  mapper = MapperL (CV_32FC2,
- * width*height*2 floats), Q 4x4 and R 3x3 row-major doubles, host memory.     */
+ * width*height*2 floats; NULL = the device-resident MapperL made by
+ * sv_update_mapper), Q 4x4 and R 3x3 row-major doubles, host memory.          */
 int sv_depth_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride,
                   const float* mapper_host, const double* Q, const double* R, float* depth_host,
                   size_t depth_stride);

@@ -638,3 +638,89 @@ int svref_wls_filter(const int16_t* disp16, const uint8_t* vis, const uint8_t* g
     free(buf);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Rectification-map generation (EXT).  StereoCamera::rectifyImages calls
+ * cv::initUndistortRectifyMap(K, Dist, Rrect, Prect, size, CV_32FC1, mapx, mapy)
+ * (lib/src/stereoCamera.cpp:569-570) and StereoCamera::updateMappings calls
+ * cv::undistortPoints(grid, grid, K, Dist, Rrect, Prect) (:2462-2463) on every frame whose
+ * kinematics changed.  Restated from OpenCV's published algorithm, double precision:
+ *   dist = {k1, k2, p1, p2, k3, k4, k5, k6} (the rational model; the module fills k1 k2 p1 p2,
+ *   DispModule.cpp:927-987); thin-prism and tilt terms are zero in this module and not modelled.
+ * initUndistortRectifyMap: iR = inv(P[:3,:3] * R); for each destination pixel (u, v) the ray
+ *   iR*(u,v,1) is normalised, distorted and projected with K.  OpenCV walks a row with running
+ *   sums (_x += iR[0] ...); the same order is kept here.
+ * undistortPoints: pixel -> normalised, 5 fixed-point iterations of the inverse distortion,
+ *   then (P[:3,:3]*R) applied and dehomogenised.
+ * ------------------------------------------------------------------------------------------ */
+static int inv3(const double* m, double* o) {
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    if (det == 0.0) return -1;
+    const double id = 1.0 / det;
+    o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+    o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
+    o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+    return 0;
+}
+static void mul3(const double* a, const double* b, double* o) {
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) o[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c];
+}
+
+/* K 3x3, dist[8], R 3x3, P 3x4 (row-major doubles) -> mapx, mapy [H][W] float */
+int svref_init_rectify_map(const double* K, const double* dist, const double* R, const double* P, int W, int H,
+                           float* mapx, float* mapy) {
+    const double P3[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    double PR[9], ir[9];
+    mul3(P3, R, PR);
+    if (inv3(PR, ir)) return -1;
+    const double fx = K[0], fy = K[4], u0 = K[2], v0 = K[5];
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4], k4 = dist[5], k5 = dist[6], k6 = dist[7];
+    for (int i = 0; i < H; i++) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < W; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double w = 1. / _w, x = _x * w, y = _y * w;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+            const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+            mapx[(size_t)i * W + j] = (float)(fx * xd + u0);
+            mapy[(size_t)i * W + j] = (float)(fy * yd + v0);
+        }
+    }
+    return 0;
+}
+
+/* the inverse mapper of updateMappings: mapper[y][x] = (x', y') rectified coordinates of the
+ * original pixel (x, y); [H][W][2] float */
+int svref_undistort_grid(const double* K, const double* dist, const double* R, const double* P, int W, int H,
+                         float* mapper) {
+    const double P3[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    double RR[9];
+    mul3(P3, R, RR);
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    if (fx == 0.0 || fy == 0.0) return -1;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double* k = dist; /* k1 k2 p1 p2 k3 k4 k5 k6 */
+    for (int yi = 0; yi < H; yi++)
+        for (int xi = 0; xi < W; xi++) {
+            double x = ((double)(float)xi - cx) * ifx, y = ((double)(float)yi - cy) * ify;
+            const double x0 = x, y0 = y;
+            for (int it = 0; it < 5; it++) {
+                const double r2 = x * x + y * y;
+                const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+                const double dX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+                const double dY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+                x = (x0 - dX) * icdist;
+                y = (y0 - dY) * icdist;
+            }
+            const double xx = RR[0] * x + RR[1] * y + RR[2], yy = RR[3] * x + RR[4] * y + RR[5];
+            const double ww = 1. / (RR[6] * x + RR[7] * y + RR[8]);
+            mapper[2 * ((size_t)yi * W + xi)] = (float)(xx * ww);
+            mapper[2 * ((size_t)yi * W + xi) + 1] = (float)(yy * ww);
+        }
+    return 0;
+}

@@ -106,6 +106,13 @@ int svref_fgs(const uint8_t* guide, size_t gs, float* img, int w, int h, float l
 int svref_wls_filter(const int16_t* disp16, const uint8_t* vis, const uint8_t* guide_rgb, int W, int H, const int roi[4],
                      float lambda, float sigma, int16_t* out16, uint8_t* out8);
 
+/* EXT cv::initUndistortRectifyMap (stereoCamera.cpp:569-570) and cv::undistortPoints on the pixel grid
+ * (stereoCamera.cpp:2462-2463).  K 3x3, dist {k1,k2,p1,p2,k3,k4,k5,k6}, R 3x3, P 3x4, row-major doubles. */
+int svref_init_rectify_map(const double* K, const double* dist, const double* R, const double* P, int W, int H,
+                           float* mapx, float* mapy);
+int svref_undistort_grid(const double* K, const double* dist, const double* R, const double* P, int W, int H,
+                         float* mapper);
+
 const char* svref_version(void);
 #ifdef __cplusplus
 }

@@ -97,6 +97,8 @@ def lib():
                                 C.c_int]
         L.svref_wls_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int * 4),
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.svref_init_rectify_map.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.svref_undistort_grid.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -258,3 +260,33 @@ def wls_filter(disp16, guide_rgb, roi, lam, sigma, vis=None):
     if rc:
         raise ValueError("svref_wls_filter failed: %d" % rc)
     return (out16, out8) if vis is not None else out16
+
+
+def _cam(K, dist, R, P):
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+    d = np.zeros(8, np.float64)
+    dd = np.asarray(dist, np.float64).ravel()
+    d[:len(dd)] = dd
+    R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    P = np.ascontiguousarray(P, np.float64).reshape(3, 4)
+    return K, d, R, P
+
+
+def init_rectify_map(K, dist, R, P, W, H):
+    """cv::initUndistortRectifyMap(..., CV_32FC1) -> (mapx, mapy)."""
+    K, d, R, P = _cam(K, dist, R, P)
+    mx, my = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+    rc = lib().svref_init_rectify_map(_ptr(K), _ptr(d), _ptr(R), _ptr(P), W, H, _ptr(mx), _ptr(my))
+    if rc:
+        raise ValueError("svref_init_rectify_map failed: %d" % rc)
+    return mx, my
+
+
+def undistort_grid(K, dist, R, P, W, H):
+    """cv::undistortPoints on the pixel grid (updateMappings) -> mapper [H][W][2]."""
+    K, d, R, P = _cam(K, dist, R, P)
+    out = np.empty((H, W, 2), np.float32)
+    rc = lib().svref_undistort_grid(_ptr(K), _ptr(d), _ptr(R), _ptr(P), W, H, _ptr(out))
+    if rc:
+        raise ValueError("svref_undistort_grid failed: %d" % rc)
+    return out

@@ -48,7 +48,9 @@ struct sv_ctx {
     Buf rect_l, rect_r;      // u8 [H][W][3] rectified
     Buf gray_l, gray_r;      // u8 [H][W]
     Buf maps[4];             // f32 [H][W]
-    Buf mapper;              // f32 [H][W][2]
+    Buf mapper;              // f32 [H][W][2] staging for sv_depth_host with a caller-supplied mapper
+    Buf mapper_lr[2];        // f32 [H][W][2] MapperL / MapperR made by sv_update_mapper
+    bool have_mapper[2] = {false, false};
     Buf depth;               // f32 [H][W]
     Buf d16tmp;              // i16 [H][W] staging for host helper entry points
     Buf vis;                 // u8 [H][W]
@@ -56,7 +58,8 @@ struct sv_ctx {
     Buf wls_lut, wls_wh, wls_wv, wls_cur, wls_tmp;  // WLS: weight table, edge weights, work images (float)
     Buf wls_g, wls_v, wls_o16, wls_o8;              // WLS host entry point staging
     float wls_lut_sigma = -1.0f;                    // sigma the device table was built for
-    bool have_maps = false;
+    bool have_maps = false;  // both cameras
+    bool have_map[2] = {false, false};
 
     // stage timing: a ring of event sets, one set per compute call, read back (and averaged)
     // only in sv_get_timings so that recording never synchronises the stream
@@ -278,6 +281,38 @@ int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff, int nb) {
     return SV_OK;
 }
 
+int inv3(const double* m, double* o) {
+    const double a = m[0], b = m[1], cc = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + cc * C;
+    if (det == 0.0) return -1;
+    const double id = 1.0 / det;
+    o[0] = A * id; o[1] = -(b * i - cc * h) * id; o[2] = (b * f - cc * e) * id;
+    o[3] = B * id; o[4] = (a * i - cc * g) * id;  o[5] = -(a * f - cc * d) * id;
+    o[6] = C * id; o[7] = -(a * h - b * g) * id;  o[8] = (a * e - b * d) * id;
+    return 0;
+}
+
+// K 3x3, dist[n_dist <= 8], R 3x3, P 3x4 -> kernel argument; inverse = true for initUndistortRectifyMap
+int cam_model(sv_ctx* c, const double* K, const double* dist, int n_dist, const double* R, const double* P, bool inverse,
+              svk::CamModel* out) {
+    if (!K || !R || !P || (n_dist > 0 && !dist)) return fail(c, SV_ERR_INVALID_ARG, "NULL camera matrix");
+    if (n_dist < 0 || n_dist > 8) return fail(c, SV_ERR_UNSUPPORTED, "distortion model with %d coefficients (0..8 supported: k1 k2 p1 p2 k3 k4 k5 k6)", n_dist);
+    if (K[0] == 0.0 || K[4] == 0.0) return fail(c, SV_ERR_INVALID_ARG, "zero focal length");
+    const double P3[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    double PR[9];
+    for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 3; q++) PR[3 * r + q] = P3[3 * r] * R[q] + P3[3 * r + 1] * R[3 + q] + P3[3 * r + 2] * R[6 + q];
+    if (inverse) {
+        if (inv3(PR, out->m)) return fail(c, SV_ERR_INVALID_ARG, "P*R is singular");
+    } else {
+        for (int i = 0; i < 9; i++) out->m[i] = PR[i];
+    }
+    out->fx = K[0]; out->fy = K[4]; out->cx = K[2]; out->cy = K[5];
+    for (int i = 0; i < 8; i++) out->k[i] = i < n_dist ? dist[i] : 0.0;
+    return SV_OK;
+}
+
 // computeROI2 (StereoMatcher.cpp:12-29)
 void wls_roi(const sv_ctx* c, int roi[4]) {
     const int bs2 = c->prm.block_size / 2;
@@ -463,7 +498,7 @@ int sv_destroy(sv_ctx* c) {
             (void)hipStreamSynchronize(c->stream);
             Buf* all[] = {&c->img_l, &c->img_r, &c->stat_l, &c->stat_r, &c->C, &c->S, &c->rec,
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
-                          &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->depth, &c->d16tmp, &c->vis,
+                          &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->mapper_lr[0], &c->mapper_lr[1], &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt, &c->wls_lut, &c->wls_wh, &c->wls_wv, &c->wls_cur, &c->wls_tmp, &c->wls_g,
                           &c->wls_v, &c->wls_o16, &c->wls_o8};
             for (Buf* b : all) release(*b);
@@ -570,7 +605,68 @@ int sv_upload_maps_host(sv_ctx* c, const float* mlx, const float* mly, const flo
         HIPCHK(c, hipMemcpyAsync(c->maps[i].p, src[i], bytes, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_maps = true;
+    c->have_maps = c->have_map[0] = c->have_map[1] = true;
+    return SV_OK;
+}
+
+int sv_init_rectify_map(sv_ctx* c, int which, const double* K, const double* dist, int n_dist, const double* R, const double* P) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (which < 0 || which > 1) return fail(c, SV_ERR_INVALID_ARG, "which must be 0 (left) or 1 (right)");
+    svk::CamModel cm;
+    int rc = cam_model(c, K, dist, n_dist, R, P, true, &cm);
+    if (rc) return rc;
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    const size_t bytes = (size_t)c->W * c->H * 4;
+    if ((rc = ensure(c, c->maps[2 * which], bytes))) return rc;
+    if ((rc = ensure(c, c->maps[2 * which + 1], bytes))) return rc;
+    const size_t lds = (size_t)c->W * 3 * sizeof(double);
+    if (lds > 160 * 1024) return fail(c, SV_ERR_UNSUPPORTED, "image width %d too large for the row buffer of the map kernel", c->W);
+    if (lds > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_init_rectify_map), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(svk::k_init_rectify_map, dim3(c->H), dim3(256), lds, c->stream,
+                       (float*)c->maps[2 * which].p, (float*)c->maps[2 * which + 1].p, c->W, cm);
+    HIPCHK(c, hipGetLastError());
+    c->have_map[which] = true;
+    c->have_maps = c->have_map[0] && c->have_map[1];
+    return SV_OK;
+}
+
+int sv_update_mapper(sv_ctx* c, int which, const double* K, const double* dist, int n_dist, const double* R, const double* P) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (which < 0 || which > 1) return fail(c, SV_ERR_INVALID_ARG, "which must be 0 (left) or 1 (right)");
+    svk::CamModel cm;
+    int rc = cam_model(c, K, dist, n_dist, R, P, false, &cm);
+    if (rc) return rc;
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    if ((rc = ensure(c, c->mapper_lr[which], (size_t)c->W * c->H * 8))) return rc;
+    hipLaunchKernelGGL(svk::k_undistort_grid, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream,
+                       (float2*)c->mapper_lr[which].p, c->W, c->H, cm);
+    HIPCHK(c, hipGetLastError());
+    c->have_mapper[which] = true;
+    return SV_OK;
+}
+
+int sv_get_maps_host(sv_ctx* c, int which, float* mapx, float* mapy) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (which < 0 || which > 1 || !mapx || !mapy) return fail(c, SV_ERR_INVALID_ARG, "bad argument");
+    if (!c->have_map[which]) return fail(c, SV_ERR_NO_MAPS, "no rectification map for this camera yet");
+    DevGuard g(c->device);
+    const size_t bytes = (size_t)c->W * c->H * 4;
+    HIPCHK(c, hipMemcpyAsync(mapx, c->maps[2 * which].p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mapy, c->maps[2 * which + 1].p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_get_mapper_host(sv_ctx* c, int which, float* mapper) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (which < 0 || which > 1 || !mapper) return fail(c, SV_ERR_INVALID_ARG, "bad argument");
+    if (!c->have_mapper[which]) return fail(c, SV_ERR_NO_MAPS, "no mapper for this camera yet (sv_update_mapper)");
+    DevGuard g(c->device);
+    HIPCHK(c, hipMemcpyAsync(mapper, c->mapper_lr[which].p, (size_t)c->W * c->H * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }
 
@@ -662,7 +758,11 @@ int sv_filter_speckles_dev(sv_ctx* c, int16_t* d16, int max_size, int max_diff) 
 
 int sv_depth_dev(sv_ctx* c, const int16_t* d16, const float* mapper, const double* Q, const double* R, float* depth) {
     if (!c) return SV_ERR_INVALID_ARG;
-    if (!d16 || !mapper || !Q || !R || !depth) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (!d16 || !Q || !R || !depth) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (!mapper) {
+        if (!c->have_mapper[0]) return fail(c, SV_ERR_NO_MAPS, "no mapper: pass one or call sv_update_mapper(ctx, 0, ...)");
+        mapper = (const float*)c->mapper_lr[0].p;
+    }
     DevGuard g(c->device);
     svk::DepthCoef k;
     k.r02 = (float)R[2]; k.r12 = (float)R[5]; k.r22 = (float)R[8];
@@ -677,17 +777,21 @@ int sv_depth_dev(sv_ctx* c, const int16_t* d16, const float* mapper, const doubl
 int sv_depth_host(sv_ctx* c, const int16_t* d16, size_t dstride, const float* mapper, const double* Q, const double* R,
                   float* depth, size_t ostride) {
     if (!c) return SV_ERR_INVALID_ARG;
-    if (!d16 || !mapper || !Q || !R || !depth) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (!d16 || !Q || !R || !depth) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
     const size_t W = c->W, H = c->H;
     if (dstride < 2 * W || ostride < 4 * W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
     DevGuard g(c->device);
     int rc;
     if ((rc = ensure(c, c->d16tmp, W * H * 2))) return rc;
-    if ((rc = ensure(c, c->mapper, W * H * 8))) return rc;
     if ((rc = ensure(c, c->depth, W * H * 4))) return rc;
     HIPCHK(c, copy2d(c->d16tmp.p, 2 * W, d16, dstride, 2 * W, H, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->mapper.p, mapper, W * H * 8, hipMemcpyHostToDevice, c->stream));
-    if ((rc = sv_depth_dev(c, (const int16_t*)c->d16tmp.p, (const float*)c->mapper.p, Q, R, (float*)c->depth.p))) return rc;
+    const float* mdev = nullptr;  // NULL: the device-resident MapperL of sv_update_mapper
+    if (mapper) {
+        if ((rc = ensure(c, c->mapper, W * H * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->mapper.p, mapper, W * H * 8, hipMemcpyHostToDevice, c->stream));
+        mdev = (const float*)c->mapper.p;
+    }
+    if ((rc = sv_depth_dev(c, (const int16_t*)c->d16tmp.p, mdev, Q, R, (float*)c->depth.p))) return rc;
     HIPCHK(c, copy2d(depth, ostride, c->depth.p, 4 * W, 4 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;

@@ -1008,4 +1008,68 @@ __global__ __launch_bounds__(64) void k_fgs_vpass(float* __restrict__ cur, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rectification-map generation.  The module marks the camera as changed on
+// every frame (DispModule.cpp:684 -> stereoCamera.cpp:1505-1536), so rectifyImages re-runs
+// cv::initUndistortRectifyMap twice (stereoCamera.cpp:569-570) and updateMappings re-runs
+// cv::undistortPoints over the whole pixel grid twice (:2462-2463) per frame on one CPU thread.
+// Here both are per-pixel FP64 kernels fed by the 3x3 / 3x4 matrices; the maps never leave HBM.
+// ---------------------------------------------------------------------------------------------
+struct CamModel {
+    double m[9];            // inv(P[:3,:3]*R) for the forward map, P[:3,:3]*R for the inverse mapper
+    double fx, fy, cx, cy;  // camera matrix K
+    double k[8];            // k1 k2 p1 p2 k3 k4 k5 k6
+};
+
+// Result of cv::initUndistortRectifyMap(K, Dist, R, P, size, CV_32FC1): one workgroup per
+// destination row.  OpenCV walks a row with running sums (_x += ir[0], ...), whose rounding a
+// closed form does not reproduce, so three lanes first lay the sums of the row down in LDS in that
+// order (W dependent adds each, a few microseconds), then every lane distorts its pixels.
+__global__ __launch_bounds__(256) void k_init_rectify_map(float* __restrict__ mapx, float* __restrict__ mapy, int W, CamModel c) {
+    extern __shared__ double rs[];  // [3][W]
+    const int i = blockIdx.x;
+    if (threadIdx.x < 3) {
+        const int t = threadIdx.x;
+        double v = i * c.m[3 * t + 1] + c.m[3 * t + 2];
+        const double inc = c.m[3 * t];
+        double* o = rs + (size_t)t * W;
+        for (int j = 0; j < W; j++, v += inc) o[j] = v;
+    }
+    __syncthreads();
+    const double k1 = c.k[0], k2 = c.k[1], p1 = c.k[2], p2 = c.k[3], k3 = c.k[4], k4 = c.k[5], k5 = c.k[6], k6 = c.k[7];
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        const double w = 1. / rs[2 * (size_t)W + j], x = rs[j] * w, y = rs[(size_t)W + j] * w;
+        const double x2 = x * x, y2 = y * y;
+        const double r2 = x2 + y2, _2xy = 2 * x * y;
+        const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+        const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+        const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+        mapx[(size_t)i * W + j] = (float)(c.fx * xd + c.cx);
+        mapy[(size_t)i * W + j] = (float)(c.fy * yd + c.cy);
+    }
+}
+
+// Result of cv::undistortPoints(grid, grid, K, Dist, R, P) on the pixel grid (updateMappings):
+// MapperL / MapperR, CV_32FC2.  Five fixed-point iterations of the inverse distortion per pixel.
+__global__ __launch_bounds__(256) void k_undistort_grid(float2* __restrict__ mapper, int W, int H, CamModel c) {
+    const int xi = blockIdx.x * blockDim.x + threadIdx.x, yi = blockIdx.y;
+    if (xi >= W) return;
+    const double ifx = 1. / c.fx, ify = 1. / c.fy;
+    double x = ((double)xi - c.cx) * ifx, y = ((double)yi - c.cy) * ify;
+    const double x0 = x, y0 = y;
+    const double* k = c.k;
+#pragma unroll 1
+    for (int it = 0; it < 5; it++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        const double dX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+        const double dY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+        x = (x0 - dX) * icdist;
+        y = (y0 - dY) * icdist;
+    }
+    const double xx = c.m[0] * x + c.m[1] * y + c.m[2], yy = c.m[3] * x + c.m[4] * y + c.m[5];
+    const double ww = 1. / (c.m[6] * x + c.m[7] * y + c.m[8]);
+    mapper[(size_t)yi * W + xi] = make_float2((float)(xx * ww), (float)(yy * ww));
+}
+
 }  // namespace svk

@@ -30,6 +30,7 @@ EXPORTS = (
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
     "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host",
+    "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
     "sv_algorithmic_bytes", "sv_last_error", "sv_version")
 
@@ -100,6 +101,10 @@ def load():
     L.sv_wls_roi.argtypes = [vp, C.POINTER(C.c_int * 4)]
     L.sv_filter_wls_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.sv_filter_wls_host.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz]
+    L.sv_init_rectify_map.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+    L.sv_update_mapper.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+    L.sv_get_maps_host.argtypes = [vp, i32, vp, vp]
+    L.sv_get_mapper_host.argtypes = [vp, i32, vp]
     L.sv_set_debug.argtypes = [vp, i32]
     L.sv_debug_read_volume_host.argtypes = [vp, i32, vp, sz]
     L.sv_debug_read_plane_host.argtypes = [vp, i32, vp]
@@ -210,14 +215,43 @@ class Matcher:
         return out
 
     def depth(self, disp16, mapper, Q, R):
+        """mapper None = the device-resident MapperL made by update_mapper(0, ...)."""
         d = np.ascontiguousarray(disp16, np.int16)
-        mapper = np.ascontiguousarray(mapper, np.float32)
         Q = np.ascontiguousarray(Q, np.float64)
         R = np.ascontiguousarray(R, np.float64)
-        assert mapper.shape == (self.H, self.W, 2) and Q.shape == (4, 4) and R.shape == (3, 3)
+        assert Q.shape == (4, 4) and R.shape == (3, 3)
+        if mapper is not None:
+            mapper = np.ascontiguousarray(mapper, np.float32)
+            assert mapper.shape == (self.H, self.W, 2)
         out = np.empty((self.H, self.W), np.float32)
-        self._chk(self._L.sv_depth_host(self._h, _ptr(d), 2 * self.W, _ptr(mapper), _ptr(Q), _ptr(R), _ptr(out),
-                                        4 * self.W))
+        self._chk(self._L.sv_depth_host(self._h, _ptr(d), 2 * self.W, _ptr(mapper) if mapper is not None else None,
+                                        _ptr(Q), _ptr(R), _ptr(out), 4 * self.W))
+        return out
+
+    @staticmethod
+    def _cam(K, dist, R, P):
+        K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+        d = np.ascontiguousarray(np.asarray(dist, np.float64).ravel())
+        R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+        P = np.ascontiguousarray(P, np.float64).reshape(3, 4)
+        return K, d, R, P
+
+    def init_rectify_map(self, which, K, dist, R, P):
+        K, d, R, P = self._cam(K, dist, R, P)
+        self._chk(self._L.sv_init_rectify_map(self._h, which, _ptr(K), _ptr(d), len(d), _ptr(R), _ptr(P)))
+
+    def update_mapper(self, which, K, dist, R, P):
+        K, d, R, P = self._cam(K, dist, R, P)
+        self._chk(self._L.sv_update_mapper(self._h, which, _ptr(K), _ptr(d), len(d), _ptr(R), _ptr(P)))
+
+    def maps(self, which):
+        mx, my = np.empty((self.H, self.W), np.float32), np.empty((self.H, self.W), np.float32)
+        self._chk(self._L.sv_get_maps_host(self._h, which, _ptr(mx), _ptr(my)))
+        return mx, my
+
+    def mapper(self, which):
+        out = np.empty((self.H, self.W, 2), np.float32)
+        self._chk(self._L.sv_get_mapper_host(self._h, which, _ptr(out)))
         return out
 
     def wls_roi(self):

@@ -100,3 +100,33 @@ def rectify_maps(W, H, which=0):
     mx = xr * s * f + cx + (0.3 if which else -0.2)
     my = yr * s * f + cy
     return mx.astype(np.float32), my.astype(np.float32)
+
+
+def rodrigues(v):
+    """Rotation matrix of the rotation vector v (what cv::Rodrigues returns)."""
+    v = np.asarray(v, np.float64)
+    th = np.linalg.norm(v)
+    if th == 0:
+        return np.eye(3)
+    k = v / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def camera(W, H, which=0):
+    """Synthetic calibrated camera of SURVEY 8(d) (config C3): K with f = 0.7 W, radial + tangential
+    distortion, a small rectifying rotation and the rectified projection P (right camera: baseline
+    term in P[0][3], as cv::stereoRectify returns it)."""
+    f = 0.7 * W
+    cx, cy = W / 2 - 0.5, H / 2 - 0.5
+    if which == 0:
+        K = np.array([[f, 0, cx], [0, f, cy], [0, 0, 1]], np.float64)
+        dist = np.array([-0.05, 0.01, 1e-3, 1e-3], np.float64)
+        R = rodrigues([0.005, -0.01, 0.0025])
+        P = np.array([[f, 0, cx, 0], [0, f, cy, 0], [0, 0, 1, 0]], np.float64)
+    else:
+        K = np.array([[f * 1.01, 0, cx + 2.0], [0, f * 1.008, cy - 1.5], [0, 0, 1]], np.float64)
+        dist = np.array([-0.045, 0.012, -8e-4, 1.2e-3, 1e-3], np.float64)
+        R = rodrigues([-0.005, 0.01, -0.0025])
+        P = np.array([[f, 0, cx, -0.068 * f], [0, f, cy, 0], [0, 0, 1, 0]], np.float64)
+    return K, dist, R, P
