@@ -380,7 +380,9 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     // Fusing WTA into the last path saves one volume write + read but triples that launch's
     // instruction count per step; with few frames in flight the path kernels are latency-bound
     // (one wave per SIMD or less), so the fusion only pays once the batch fills the chip.
-    const bool fuse = !c->debug && (c->force_fuse || nb >= c->fuse_wta_min_batch);
+    // Measured crossover at 640x480 D=128: 6 frames x 512 chains; scaled by the chain count so that
+    // one 1920x1080 frame (1664 chains per launch) counts as what it is.
+    const bool fuse = !c->debug && (c->force_fuse || (long)nb * (W - D) >= (long)c->fuse_wta_min_batch * 512);
     mark();
     // 1. prefilter + BT statistics
     hipLaunchKernelGGL(svk::k_stats, dim3((W + 255) / 256, H, 2 * nb), dim3(256), 0, c->stream, left, right, (uint2*)c->stat_l.p,

@@ -95,3 +95,23 @@ def test_batched_launch_matches_oracle(gpu):
     with pytest.raises(svhip.SvError):
         m.compute_gray_batch_dev(nb + 1, lt, rt, out)
     m.close()
+
+
+@pytest.mark.parametrize("W,H,D,seed", [(640, 480, 128, 202), (1920, 1080, 256, 404)])
+def test_full_size_configs_bit_exact(gpu, W, H, D, seed):
+    """BASELINE.json configs C2 and C4 at full size: the oracle needs 0.4 s / ~6 s per frame, so the
+    comparison is direct; plus the shift property (right = left shifted by k -> disparity 16k)."""
+    left, right, _ = synth.stereo_pair(seed, W, H, D)
+    ph, po = _params(D, 8)
+    m = svhip.Matcher(W, H, ph)
+    got = m.compute_gray(left, right)
+    assert np.array_equal(got, svref.sgbm(left, right, po))
+    m.set_debug(2)
+    assert np.array_equal(m.compute_gray(left, right), got), "fused-WTA path differs at full size"
+    m.set_debug(0)
+    k = D // 3
+    shifted = np.roll(left, -k, axis=1)
+    d = m.compute_gray(left, shifted)
+    inner = d[16:-16, D + 16:W - k - 16]
+    assert (inner == 16 * k).mean() > 0.99
+    m.close()
