@@ -128,6 +128,11 @@ int sv_get_params(const sv_ctx* ctx, sv_params* params);
  * stream and cudaDeviceSynchronize after every kernel, bova_sgm.cu:92-130).  */
 int sv_set_stream(sv_ctx* ctx, void* hip_stream);
 
+/* Waits for everything enqueued on the context stream and reports deferred
+ * device-side errors of the *_dev entry points (the reference synchronises
+ * after every kernel instead, bova_sgm.cu:92-130).                            */
+int sv_synchronize(sv_ctx* ctx);
+
 /* Replaces zy_remap / compute_disparity (main.cpp:106-109, bova_sgm.cu:43-328):
  * 8-bit gray rectified pair in host memory -> disparity16 in host memory.
  * Columns [0, D) are written as SV_INVALID_DISP_SCALED (the reference leaves
@@ -245,8 +250,11 @@ int sv_depth_dev(sv_ctx* ctx, const int16_t* disp16_dev, const float* mapper_dev
  * debug mode.  sv_set_debug modes: 0 = production (batches of >= 6 frames fuse
  * WTA into the last path, which then keeps the finished S in registers and
  * never stores it; smaller batches, being latency-bound, run WTA as its own
- * kernel), 1 = debug (S always materialised), 2 = WTA fused whatever the batch
- * size (so that tests can exercise the fused kernels on one frame).           */
+ * kernel; batches of >= 8 frames with D <= 128 and all four paths of a sweep
+ * enabled run the fused sweep kernels, four paths per pass over C),
+ * 1 = debug (per-path kernels, S always materialised), 2 = WTA fused into the
+ * last path whatever the batch size, 3 = fused sweeps whatever the batch size,
+ * 4 = never the fused sweeps (2-4 let tests exercise each variant on one frame). */
 int sv_set_debug(sv_ctx* ctx, int mode);
 int sv_debug_read_volume_host(sv_ctx* ctx, int which, int16_t* vol_host, size_t n_elems);
 /* which: 0 = disp before LR check, 1 = raw integer disparity, 2 = minS,

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sv_kernels.hip.h"
+#include "sv_sweep.hip.h"
 
 namespace {
 
@@ -42,6 +43,12 @@ struct sv_ctx {
     Buf rec;                 // WTA records {disp16, raw, minS, 0} [H][W] x 8 bytes
     bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
     bool force_fuse = false; // sv_set_debug(ctx, 2): WTA fused into the last path whatever the batch size
+    // fused four-path sweeps (sv_sweep.hip.h)
+    Buf sw_handoff, sw_progress, sw_sink;
+    unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
+    int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
+    int sweep_min_batch = 8;
+    int n_cu = 256;
     int fuse_wta_min_batch = 6;  // batches below this run WTA as its own kernel (see run_sgm; crossover measured at 640x480 D=128)
     Buf disp_lr, out;        // i16 [H][W]
     Buf rgb_l, rgb_r;        // u8 [H][W][3] input staging
@@ -265,6 +272,67 @@ void launch_wta(sv_ctx* c, int nb) {
     }
 }
 
+// One fused sweep (four paths) over nb frames.  second = false: paths R, DR, D, DL, S is written;
+// second = true: paths L, UL, U, UR on mirrored coordinates, S is read, WTA records are written.
+template <int N>
+int launch_sweep_n(sv_ctx* c, bool second, int nb) {
+    const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
+    const int n_bands = (H + svk::SW_ROWS - 1) / svk::SW_ROWS;
+    int n_groups = c->n_cu / n_bands;
+    if (n_groups < 1) n_groups = 1;
+    if (n_groups > nb) n_groups = nb;
+    const int fpg = (nb + n_groups - 1) / n_groups;
+    if ((long)fpg * W1 > (1L << 30)) return fail(c, SV_ERR_UNSUPPORTED, "batch too large for the sweep kernel");
+    const int ho_px = (fpg * W1 + 15) & ~15;
+    constexpr int REC = svk::sweep_rec_words<N>();
+    const int grid = n_groups * n_bands;
+    int rc;
+    if ((rc = ensure(c, c->sw_handoff, (size_t)n_groups * (n_bands > 1 ? n_bands - 1 : 1) * (size_t)(ho_px + 1) * REC * 4))) return rc;
+    if ((rc = ensure(c, c->sw_progress, (size_t)n_groups * n_bands * 4))) return rc;
+    if ((rc = ensure(c, c->sw_sink, (size_t)grid * 1024 * 16))) return rc;
+    constexpr size_t lds = svk::sweep_lds_bytes<N>();
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[second]) {
+        const void* fn = second ? reinterpret_cast<const void*>(&svk::k_sweep<N, true>) : reinterpret_cast<const void*>(&svk::k_sweep<N, false>);
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[second] = true;
+    }
+    HIPCHK(c, hipMemsetAsync(c->sw_progress.p, 0, (size_t)n_groups * n_bands * 4, c->stream));
+    svk::SweepArgs a;
+    a.C = (const uint32_t*)c->C.p;
+    a.S = (uint32_t*)c->S.p;
+    a.rec = (uint2*)c->rec.p;
+    a.handoff = (unsigned long long*)c->sw_handoff.p;
+    a.progress = (unsigned int*)c->sw_progress.p;
+    a.error = c->sw_error;
+    a.sink = (uint32_t*)c->sw_sink.p;
+    a.W1 = W1; a.H = H; a.W = c->W;
+    a.P1P1 = (uint32_t)c->prm.P1 * 0x10001u;
+    a.P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
+    a.uniq = c->prm.uniqueness_ratio;
+    a.n_frames = nb; a.n_groups = n_groups; a.n_bands = n_bands; a.ho_px = ho_px;
+    if (second) hipLaunchKernelGGL((svk::k_sweep<N, true>), dim3(grid), dim3(1024), lds, c->stream, a);
+    else hipLaunchKernelGGL((svk::k_sweep<N, false>), dim3(grid), dim3(1024), lds, c->stream, a);
+    return SV_OK;
+}
+int launch_sweep(sv_ctx* c, bool second, int nb) {
+    switch (c->prm.num_disparities / 32) {
+        case 1: return launch_sweep_n<1>(c, second, nb);
+        case 2: return launch_sweep_n<2>(c, second, nb);
+        case 3: return launch_sweep_n<3>(c, second, nb);
+        case 4: return launch_sweep_n<4>(c, second, nb);
+        default: return fail(c, SV_ERR_UNSUPPORTED, "fused sweeps need D <= 128");
+    }
+}
+// a sweep kernel gave up waiting for its neighbour band (never expected; reported at the next sync point)
+int check_sweep_error(sv_ctx* c) {
+    if (c->sw_error && *c->sw_error) {
+        *c->sw_error = 0;
+        return fail(c, SV_ERR_HIP, "fused sweep kernel timed out waiting for a neighbouring band; results of that call are invalid");
+    }
+    return SV_OK;
+}
+
 int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff, int nb) {
     const int n = c->W * c->H * nb;
     int rc;
@@ -394,21 +462,43 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         if (rc) return rc;
     }
     mark();
-    // 3. path aggregation (first path initialises S)
-    // (first path initialises S; unless debugging, the last path carries WTA and never stores S)
+    // 3. path aggregation.  Large batches: fused sweeps (four paths per pass over C, sv_sweep.hip.h).
+    // Otherwise one launch per path: the first one initialises S and, when `fuse`, the last one
+    // carries WTA and never stores S.
+    bool wta_done = false;
     {
-        int last = 7;
-        while (!(p.path_mask & (1u << last))) last--;
+        const bool sweep_ok = !c->debug && D <= 128 && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= c->sweep_min_batch);
+        const bool sw1 = sweep_ok && (p.path_mask & 0x0Fu) == 0x0Fu;
+        const bool sw2 = sw1 && (p.path_mask & 0xF0u) == 0xF0u;
+        uint32_t rest = p.path_mask;
         bool first = true;
-        for (int dir = 0; dir < 8; dir++)
-            if (p.path_mask & (1u << dir)) {
-                launch_agg(c, dir, (first ? 1 : 0) | ((dir == last && fuse) ? 2 : 0), nb);
-                first = false;
-            }
+        if (sw1) {
+            int rc = launch_sweep(c, false, nb);
+            if (rc) return rc;
+            rest &= ~0x0Fu;
+            first = false;
+        }
+        if (sw2) {
+            int rc = launch_sweep(c, true, nb);
+            if (rc) return rc;
+            rest = 0;
+            wta_done = true;
+        }
+        if (rest) {
+            int last = 7;
+            while (!(rest & (1u << last))) last--;
+            for (int dir = 0; dir < 8; dir++)
+                if (rest & (1u << dir)) {
+                    const bool fl = dir == last && fuse;
+                    launch_agg(c, dir, (first ? 1 : 0) | (fl ? 2 : 0), nb);
+                    first = false;
+                    wta_done = wta_done || fl;
+                }
+        }
     }
     mark();
-    // 4. WTA as its own kernel when it was not fused into the last path
-    if (!fuse) launch_wta(c, nb);
+    // 4. WTA as its own kernel when it was not fused into the last path / second sweep
+    if (!wta_done) launch_wta(c, nb);
     mark();
     // 5. LR check, median, speckle
     {
@@ -488,7 +578,13 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     for (int r = 0; r < sv_ctx::EV_RING; r++)
         for (int i = 0; i < sv_ctx::EV_PER; i++) HIPCHK(c, hipEventCreate(&c->ev[r][i]));
     c->ev_ok = true;
-    if (const char* e = getenv("SV_FUSE_WTA_MIN_BATCH")) c->fuse_wta_min_batch = atoi(e);  // tuning knob
+    if (const char* e = getenv("SV_FUSE_WTA_MIN_BATCH")) c->fuse_wta_min_batch = atoi(e);  // tuning knobs
+    if (const char* e = getenv("SV_SWEEP_MIN_BATCH")) c->sweep_min_batch = atoi(e);
+    if (const char* e = getenv("SV_SWEEP_MODE")) c->sweep_mode = atoi(e);
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("SV_SWEEP_NCU")) c->n_cu = atoi(e) > 0 ? atoi(e) : c->n_cu;  // tests: few groups, many frames each
+    HIPCHK(c, hipHostMalloc((void**)&c->sw_error, sizeof(unsigned int), hipHostMallocMapped));
+    *c->sw_error = 0;
     return alloc_core(c);
 }
 
@@ -502,8 +598,9 @@ int sv_destroy(sv_ctx* c) {
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->mapper_lr[0], &c->mapper_lr[1], &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt, &c->wls_lut, &c->wls_wh, &c->wls_wv, &c->wls_cur, &c->wls_tmp, &c->wls_g,
-                          &c->wls_v, &c->wls_o16, &c->wls_o8};
+                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink};
             for (Buf* b : all) release(*b);
+            if (c->sw_error) (void)hipHostFree(c->sw_error);
             if (c->ev_ok)
                 for (int r = 0; r < sv_ctx::EV_RING; r++)
                     for (int i = 0; i < sv_ctx::EV_PER; i++)
@@ -582,7 +679,7 @@ int sv_compute_gray_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_
     if ((rc = run_sgm(c, (const uint8_t*)c->img_l.p, (const uint8_t*)c->img_r.p, (int16_t*)c->out.p))) return rc;
     HIPCHK(c, copy2d(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SV_OK;
+    return check_sweep_error(c);
 }
 
 int sv_gray_from_rgb_dev(sv_ctx* c, const uint8_t* rgb_dev, uint8_t* gray_dev) {
@@ -711,7 +808,7 @@ int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t
     if ((rc = run_sgm(c, (const uint8_t*)c->gray_l.p, (const uint8_t*)c->gray_r.p, (int16_t*)c->out.p))) return rc;
     HIPCHK(c, copy2d(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SV_OK;
+    return check_sweep_error(c);
 }
 
 int sv_get_rectified_host(sv_ctx* c, int which, uint8_t* rgb, size_t stride) {
@@ -850,10 +947,19 @@ int sv_filter_wls_host(sv_ctx* c, const int16_t* d16, size_t ds, const uint8_t* 
     return SV_OK;
 }
 
+int sv_synchronize(sv_ctx* c) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_sweep_error(c);
+}
+
 int sv_set_debug(sv_ctx* c, int enable) {
     if (!c) return SV_ERR_INVALID_ARG;
     c->debug = enable == 1;
     c->force_fuse = enable == 2;
+    c->sweep_mode = enable == 3 ? 1 : (enable == 4 ? -1 : 0);
     return SV_OK;
 }
 

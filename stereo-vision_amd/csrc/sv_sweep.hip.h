@@ -1,0 +1,276 @@
+// sv_sweep.hip.h — fused SGM sweep: the four paths of one sweep in ONE pass over the cost volume.
+//
+// Result of cost_aggregation_lr + _ud_lr + _ud + _rl_ud (sgbm_cuda/aggregation.cu:60-543) for the
+// first sweep, and of the mirrored four paths of OpenCV MODE_HH's second sweep (what matchSGBM asks
+// for, StereoMatcher.cpp:409) + get_disparity (aggregation.cu:629-689) for the second.  The
+// per-path kernels (k_agg) read C and read-modify-write S once per path: 22 volume passes for
+// eight paths.  Here a sweep reads C once and writes (sweep 1) or reads (sweep 2) S once: 4 passes.
+//
+// How: the predecessors of pixel (x, y) in a sweep are (x-1, y), (x-1, y-1), (x, y-1), (x+1, y-1).
+// Give every image row its own 16-lane group that walks the row left to right, and let row y run
+// two pixels behind row y-1: at step t row y is at x = t - 2y, and everything it needs from the
+// row above was produced 1 (down-left), 2 (down) and 3 (down-right) steps earlier.  The image is a
+// systolic array of rows; the horizontal path lives in the row's own registers, the other three
+// arrive from the row above through an LDS mailbox (one record per row and step, double-buffered,
+// one workgroup barrier per step).  A workgroup holds 60 consecutive rows (15 waves) plus one
+// service wave that carries the records across the band boundary: it exports the last row's
+// records to HBM and imports the previous band's, ordered by a progress counter per band
+// (write-through sc1 stores, drained, then an sc1 counter store; sc1 polls and loads on the other
+// side: MI355X_MICROARCH.md "Valid forms", first row of the table).  Bands of one frame therefore
+// run as a pipeline, 2*60 steps apart, and a workgroup streams its band of frame after frame
+// without draining, so the 2-steps-per-row skew is paid once per launch, not once per frame.
+// The second sweep is the same kernel on coordinates mirrored in x and y; its finished S stays in
+// registers and goes straight into winner-take-all.
+#pragma once
+#include "sv_kernels.hip.h"
+
+namespace svk {
+
+constexpr int SW_ROWS = 60;   // image rows per band = compute lane-groups per workgroup (15 waves x 4)
+constexpr int SW_RING = 32;   // pixels in the import / export rings
+constexpr int SW_LEAD = 32;   // loop steps before stream pixel 0 (service pipeline warm-up), multiple of 4
+constexpr int SW_DEPTH = 4;   // global-load pipeline depth in steps
+constexpr int SW_SPIN_MAX = 1 << 18;
+
+struct SweepArgs {
+    const uint32_t* C;             // [n_frames][H][W1][D/2] packed u16 pairs
+    uint32_t* S;                   // same shape: written by sweep 1, read by sweep 2
+    uint2* rec;                    // sweep 2: WTA records [n_frames][H][W]
+    unsigned long long* handoff;   // [n_groups][n_bands - 1][ho_px + 1][REC / 2]: band-boundary records (+1 dummy)
+    unsigned int* progress;        // [n_groups][n_bands]: stream pixels exported so far (zeroed before the launch)
+    unsigned int* error;           // host-visible: set when a bounded wait ran out
+    uint32_t* sink;                // [gridDim.x * 1024 * 4] u32: target of the stores of inactive steps
+    int W1, H, W;
+    uint32_t P1P1, P2P2;
+    int uniq;
+    int n_frames, n_groups, n_bands;
+    int ho_px;                     // handoff pixels per (group, band): frames-per-group * W1, rounded up
+};
+
+template <int N>
+__host__ __device__ constexpr int sweep_rec_words() { return 3 * 16 * N + 16; }
+template <int N>
+__host__ __device__ constexpr size_t sweep_lds_bytes() {
+    return sizeof(uint32_t) * ((size_t)(2 * (SW_ROWS + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4);
+}
+
+// One SGM path update of one pixel: Lp = previous L along the path (0 and delta = P2 when the path
+// starts here), c = the pixel's costs.  Same arithmetic as k_agg's step.
+template <int N>
+__device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&lp_in)[N], uint32_t dd_in, bool fresh,
+                                           uint32_t P1P1, uint32_t P2P2, uint32_t (&L)[N], uint32_t& dd_out) {
+    const uint32_t keep = fresh ? 0u : 0xFFFFFFFFu;
+    const uint32_t dd = fresh ? P2P2 : dd_in;
+    uint32_t r[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = lp_in[k] & keep;
+    const uint32_t prevHi = dpp<DPP_ROW_SHR1>(0x7FFF7FFFu, r[N - 1]);
+    const uint32_t nextLo = dpp<DPP_ROW_SHL1>(0x7FFF7FFFu, r[0]);
+    uint32_t m[N + 1];
+    m[0] = __builtin_amdgcn_alignbit(r[0], prevHi, 16);
+#pragma unroll
+    for (int k = 1; k < N; k++) m[k] = __builtin_amdgcn_alignbit(r[k], r[k - 1], 16);
+    m[N] = __builtin_amdgcn_alignbit(nextLo, r[N - 1], 16);
+    uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        uint32_t t = pk_add(pk_min(m[k], m[k + 1]), P1P1);
+        t = pk_min(pk_min(t, r[k]), dd);
+        L[k] = pk_sub(pk_add(c[k], t), dd);
+        mn = pk_min(mn, L[k]);
+    }
+    mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));
+    mn = row16_min_u32(mn);
+    dd_out = mn + P2P2;
+}
+
+__device__ __forceinline__ void sweep_barrier() {
+    // LDS traffic of this wave done, then the workgroup barrier.  Not __syncthreads(): that would
+    // also drain vmcnt and with it the global-load pipeline.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int N, bool SECOND>
+__global__ __launch_bounds__(1024) void k_sweep(SweepArgs a) {
+    constexpr int PXW = 16 * N, REC = sweep_rec_words<N>(), RECQ = REC / 2;
+    extern __shared__ __align__(16) uint32_t sw_lds[];
+    uint32_t* const slot = sw_lds;                              // [2][SW_ROWS + 1][REC]: slot[p][r] is read by row r
+    uint32_t* const imp = slot + 2 * (SW_ROWS + 1) * REC;       // [SW_RING][REC]: records of the previous band's last row
+    uint32_t* const expo = imp + SW_RING * REC;                 // [SW_RING][REC]: records of this band's last row
+    volatile uint32_t* const ctrl = expo + SW_RING * REC;       // [0]: abort
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 15;
+    const int band = blockIdx.x % a.n_bands, group = blockIdx.x / a.n_bands;
+    const int nfr = (a.n_frames - group + a.n_groups - 1) / a.n_groups;  // frames of this group: group, group + n_groups, ...
+    const int W1 = a.W1, H = a.H;
+    const int total_px = nfr * W1;  // length of the pixel stream of every row of this group
+    const bool compute = wave < 15;
+    const int r = compute ? wave * 4 + (lane >> 4) : 0;  // local row
+    const int yl = band * SW_ROWS + r;                    // row in sweep order
+    const bool rowok = compute && yl < H;
+    const int yp = SECOND ? H - 1 - min(yl, H - 1) : min(yl, H - 1);  // image row
+    const size_t frame_words = (size_t)H * W1 * PXW;
+    const uint32_t P1P1 = a.P1P1, P2P2 = a.P2P2;
+    uint32_t* const mysink = a.sink + ((size_t)blockIdx.x * 1024 + tid) * 4;
+
+    if (tid == 0) ctrl[0] = 0;
+    __syncthreads();
+
+    // ---- compute rows: cursors.  x < 0 until the row's turn comes; fi counts frames of the group.
+    int x = -SW_LEAD - 2 * r - 2, fi = 0;            // compute cursor at step tau = -SW_LEAD
+    int lx = x, lfi = 0;                             // load cursor, SW_DEPTH steps ahead after the prologue
+    uint32_t r0[N], d1n[N], d1r[N], d2r[N];          // own horizontal L; delayed records of the row above
+    uint32_t dd0 = P2P2, d1n_dd = P2P2, d1r_dd = P2P2, d2r_dd = P2P2;
+#pragma unroll
+    for (int k = 0; k < N; k++) r0[k] = d1n[k] = d1r[k] = d2r[k] = 0;
+    uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N];
+
+    auto advance = [&](int& cx, int& cfi) {
+        cx++;
+        const bool wrap = cx == W1;
+        cx = wrap ? 0 : cx;
+        cfi += wrap ? 1 : 0;
+    };
+    auto pixel_words = [&](int cx, int cfi) -> size_t {  // word offset of (frame, row, x) for this lane, clamped to a valid pixel
+        const int xx = min(max(cx, 0), W1 - 1), ff = min(cfi, nfr - 1);
+        const int xp = SECOND ? W1 - 1 - xx : xx;
+        return (size_t)(group + ff * a.n_groups) * frame_words + ((size_t)yp * W1 + xp) * PXW + q * N;
+    };
+    auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N]) {
+        const size_t off = pixel_words(lx, lfi);
+        load_regs<N>(a.C + off, c);
+        if (SECOND) load_regs<N>(a.S + off, s);
+        advance(lx, lfi);
+    };
+
+    // ---- service wave state
+    const bool do_import = !compute && band > 0, do_export = !compute && band < a.n_bands - 1;
+    unsigned long long* const ho_in = a.handoff + ((size_t)group * (a.n_bands - 1) + max(band - 1, 0)) * (size_t)(a.ho_px + 1) * RECQ;
+    unsigned long long* const ho_out = a.handoff + ((size_t)group * (a.n_bands - 1) + max(min(band, a.n_bands - 2), 0)) * (size_t)(a.ho_px + 1) * RECQ;
+    unsigned int* const flag_in = a.progress + (size_t)group * a.n_bands + max(band - 1, 0);
+    unsigned int* const flag_out = a.progress + (size_t)group * a.n_bands + band;
+    unsigned long long ib[SW_DEPTH][2];
+#pragma unroll
+    for (int j = 0; j < SW_DEPTH; j++) ib[j][0] = ib[j][1] = 0;
+    const bool l0 = lane < RECQ, l1 = lane + 64 < RECQ;  // this lane's two 8-byte words of a record
+
+    static_assert(N >= 1 && N <= 4, "k_sweep keeps four paths of D = 32*N disparities in registers: D <= 128");
+    const int tau_end = total_px + 2 * SW_ROWS + 4;
+    // Two loops with the same trip count and one barrier per step each: the compute waves and the
+    // service wave never share a basic block, so each body is straight-line code for the scheduler.
+    if (compute) {
+#pragma unroll
+        for (int j = 0; j < SW_DEPTH; j++) issue(cb[j], sb[j]);
+        const bool y0 = yl == 0;
+        for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
+            if (ctrl[0] != 0) break;
+#pragma unroll
+            for (int j = 0; j < SW_DEPTH; j++) {
+                const int u = tau + j - 2 * r - 2;  // stream pixel of this row at this step; (tau + j) & 1 == j & 1
+                const bool active = rowok && x >= 0 && fi < nfr;
+                // record of the row above: pixel u + 1 of its stream
+                const uint32_t* src = (r == 0) ? imp + ((u + 1) & (SW_RING - 1)) * REC
+                                               : slot + (((j + 1) & 1) * (SW_ROWS + 1) + r) * REC;
+                uint32_t in_dl[N], in_dn[N], in_dr[N];
+                load_regs<N>(src + q * N, in_dl);
+                load_regs<N>(src + PXW + q * N, in_dn);
+                load_regs<N>(src + 2 * PXW + q * N, in_dr);
+                const uint32_t dd_dl = src[3 * PXW], dd_dn = src[3 * PXW + 1], dd_dr = src[3 * PXW + 2];
+                uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
+                sweep_path<N>(cb[j], r0, dd0, x == 0, P1P1, P2P2, L0, n0);                   // horizontal
+                sweep_path<N>(cb[j], d2r, d2r_dd, y0 || x == 0, P1P1, P2P2, L1, n1);        // from (x-1, y-1)
+                sweep_path<N>(cb[j], d1n, d1n_dd, y0, P1P1, P2P2, L2, n2);                  // from (x,   y-1)
+                sweep_path<N>(cb[j], in_dl, dd_dl, y0 || x == W1 - 1, P1P1, P2P2, L3, n3);  // from (x+1, y-1)
+                // own record for the row below
+                uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
+                                                   : slot + ((j & 1) * (SW_ROWS + 1) + r + 1) * REC;
+                store_regs<N>(dst + q * N, L3);
+                store_regs<N>(dst + PXW + q * N, L2);
+                store_regs<N>(dst + 2 * PXW + q * N, L1);
+                dst[3 * PXW + q] = q == 0 ? n3 : (q == 1 ? n2 : n1);  // words 3.. of the tail are padding
+                uint32_t snew[N];
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const uint32_t s01 = pk_min(pk_add(L0[k], L1[k]), 0x7FFF7FFFu);
+                    const uint32_t s23 = pk_min(pk_add(L2[k], L3[k]), 0x7FFF7FFFu);
+                    const uint32_t s4 = pk_min(pk_add(s01, s23), 0x7FFF7FFFu);
+                    snew[k] = SECOND ? pk_min(pk_add(sb[j][k], s4), 0x7FFF7FFFu) : s4;
+                    r0[k] = L0[k];
+                    d2r[k] = d1r[k];
+                    d1r[k] = in_dr[k];
+                    d1n[k] = in_dn[k];
+                }
+                dd0 = n0;
+                d2r_dd = d1r_dd;
+                d1r_dd = dd_dr;
+                d1n_dd = dd_dn;
+                if (SECOND) {
+                    const uint2 w = wta_record<N>(snew, q, a.uniq);  // all 16 lanes hold the same record
+                    const int xp = W1 - 1 - min(max(x, 0), W1 - 1);
+                    uint2* o = active ? a.rec + ((size_t)(group + min(fi, nfr - 1) * a.n_groups) * H + yp) * a.W + xp + 32 * N
+                                      : reinterpret_cast<uint2*>(mysink);
+                    *o = w;
+                } else {
+                    uint32_t* o = active ? a.S + pixel_words(x, fi) : mysink;
+                    store_regs<N>(o, snew);
+                }
+                advance(x, fi);
+                issue(cb[j], sb[j]);
+                sweep_barrier();
+            }
+        }
+    } else {
+        bool aborted = false;
+        for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
+            if (ctrl[0] != 0) { aborted = true; break; }
+#pragma unroll
+            for (int j = 0; j < SW_DEPTH; j++) {
+                const int t = tau + j;
+                // import: pixel t + 2 of the previous band's last row (loaded four steps ago) -> ring;
+                // row 0 reads pixel t' - 1 at step t'.
+                if (do_import) {
+                    if ((t & 15) == 0 && t + 23 > 0) {
+                        const unsigned need = (unsigned)min(t + 23, total_px);
+                        int spins = 0;
+                        while (__hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                            __builtin_amdgcn_s_sleep(16);
+                            if (++spins > SW_SPIN_MAX) {
+                                ctrl[0] = 1;
+                                if (lane == 0) __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                break;
+                            }
+                        }
+                    }
+                    uint32_t* w = imp + ((t + 2) & (SW_RING - 1)) * REC;
+                    if (l0) reinterpret_cast<unsigned long long*>(w)[lane] = ib[j][0];
+                    if (l1) reinterpret_cast<unsigned long long*>(w)[lane + 64] = ib[j][1];
+                    const int p = t + 6;
+                    const unsigned long long* g = ho_in + (size_t)((p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
+                    if (l0) ib[j][0] = __hip_atomic_load(g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (l1) ib[j][1] = __hip_atomic_load(g + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // export: the record row SW_ROWS-1 wrote in the previous step (pixel t - 1 - 2*SW_ROWS)
+                if (do_export) {
+                    const int p = t - 1 - 2 * SW_ROWS;
+                    const uint32_t* e = expo + (p & (SW_RING - 1)) * REC;
+                    unsigned long long* g = ho_out + (size_t)((p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
+                    if (l0) __hip_atomic_store(g + lane, reinterpret_cast<const unsigned long long*>(e)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (l1) __hip_atomic_store(g + lane + 64, reinterpret_cast<const unsigned long long*>(e)[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((t & 15) == 8) {
+                        // every memory operation of this wave done (stores written through), then the counter
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const int done = min(max(p + 1, 0), total_px);
+                        if (lane == 0) __hip_atomic_store(flag_out, (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                sweep_barrier();
+            }
+        }
+        if (do_export && !aborted) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(flag_out, (unsigned)total_px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace svk
