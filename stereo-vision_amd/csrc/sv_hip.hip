@@ -44,10 +44,13 @@ struct sv_ctx {
     bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
     bool force_fuse = false; // sv_set_debug(ctx, 2): WTA fused into the last path whatever the batch size
     // fused four-path sweeps (sv_sweep.hip.h)
-    Buf sw_handoff, sw_progress, sw_sink;
+    Buf sw_handoff, sw_progress, sw_sink, sw_prof;
+    int sw_prof_n = 0;
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 8;
+    bool attr_sweep[2][4][2] = {}, attr_cost[8] = {};
+    int sweep_cw = 7;                  // compute waves per sweep workgroup (7: two workgroups per CU, 15: one)
     int n_cu = 256;
     int fuse_wta_min_batch = 6;  // batches below this run WTA as its own kernel (see run_sgm; crossover measured at 640x480 D=128)
     Buf disp_lr, out;        // i16 [H][W]
@@ -221,7 +224,7 @@ int launch_cost_n(sv_ctx* c, int nb) {
     const sv_params& p = c->prm;
     const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
     const svk::CostLds lay = svk::cost_lds_layout(D, r);
-    static bool attr_set[8] = {false};  // per N; the attribute is per kernel symbol (process-wide)
+    bool* attr_set = c->attr_cost;  // per context: the attribute is per device
     if (lay.total > 48 * 1024 && !attr_set[N - 1]) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_cost<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024));
@@ -274,14 +277,25 @@ void launch_wta(sv_ctx* c, int nb) {
 
 // One fused sweep (four paths) over nb frames.  second = false: paths R, DR, D, DL, S is written;
 // second = true: paths L, UL, U, UR on mirrored coordinates, S is read, WTA records are written.
-template <int N>
+template <int N, int CW>
 int launch_sweep_n(sv_ctx* c, bool second, int nb) {
+    constexpr int ROWS = 4 * CW, NTHR = (CW + 1) * 64;
     const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
-    const int n_bands = (H + svk::SW_ROWS - 1) / svk::SW_ROWS;
-    int n_groups = c->n_cu / n_bands;
+    const int n_bands = (H + ROWS - 1) / ROWS;
+    constexpr size_t lds = svk::sweep_lds_bytes<N, CW>();
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2048 / NTHR) per_cu = 2048 / NTHR;
+    if (per_cu < 1) per_cu = 1;
+    int n_groups = c->n_cu * per_cu / n_bands;
     if (n_groups < 1) n_groups = 1;
     if (n_groups > nb) n_groups = nb;
-    const int fpg = (nb + n_groups - 1) / n_groups;
+    int fpg = (nb + n_groups - 1) / n_groups;
+    // a group's block of C / S must stay below 4 GiB (32-bit word offsets in the kernel)
+    const size_t frame_bytes = (size_t)H * W1 * D * 2;
+    const int fpg_max = (int)(((size_t)1 << 32) / frame_bytes) - 1;
+    if (fpg_max < 1) return fail(c, SV_ERR_UNSUPPORTED, "frame too large for the sweep kernel");
+    if (fpg > fpg_max) fpg = fpg_max;
+    n_groups = (nb + fpg - 1) / fpg;  // contiguous blocks of fpg frames; the last block may be shorter
     if ((long)fpg * W1 > (1L << 30)) return fail(c, SV_ERR_UNSUPPORTED, "batch too large for the sweep kernel");
     const int ho_px = (fpg * W1 + 15) & ~15;
     constexpr int REC = svk::sweep_rec_words<N>();
@@ -289,13 +303,12 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     int rc;
     if ((rc = ensure(c, c->sw_handoff, (size_t)n_groups * (n_bands > 1 ? n_bands - 1 : 1) * (size_t)(ho_px + 1) * REC * 4))) return rc;
     if ((rc = ensure(c, c->sw_progress, (size_t)n_groups * n_bands * 4))) return rc;
-    if ((rc = ensure(c, c->sw_sink, (size_t)grid * 1024 * 16))) return rc;
-    constexpr size_t lds = svk::sweep_lds_bytes<N>();
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[second]) {
-        const void* fn = second ? reinterpret_cast<const void*>(&svk::k_sweep<N, true>) : reinterpret_cast<const void*>(&svk::k_sweep<N, false>);
+    if ((rc = ensure(c, c->sw_sink, (size_t)grid * NTHR * 16))) return rc;
+    bool& attr_set = c->attr_sweep[second][N - 1][CW == 15];  // per context: the attribute is per device
+    if (!attr_set) {
+        const void* fn = second ? reinterpret_cast<const void*>(&svk::k_sweep<N, true, CW>) : reinterpret_cast<const void*>(&svk::k_sweep<N, false, CW>);
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[second] = true;
+        attr_set = true;
     }
     HIPCHK(c, hipMemsetAsync(c->sw_progress.p, 0, (size_t)n_groups * n_bands * 4, c->stream));
     svk::SweepArgs a;
@@ -310,19 +323,29 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     a.P1P1 = (uint32_t)c->prm.P1 * 0x10001u;
     a.P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
     a.uniq = c->prm.uniqueness_ratio;
-    a.n_frames = nb; a.n_groups = n_groups; a.n_bands = n_bands; a.ho_px = ho_px;
-    if (second) hipLaunchKernelGGL((svk::k_sweep<N, true>), dim3(grid), dim3(1024), lds, c->stream, a);
-    else hipLaunchKernelGGL((svk::k_sweep<N, false>), dim3(grid), dim3(1024), lds, c->stream, a);
+    a.n_frames = nb; a.n_groups = n_groups; a.n_bands = n_bands; a.ho_px = ho_px; a.fpg = fpg;
+    a.prof = nullptr;
+#ifdef SV_SWEEP_PROF
+    if ((rc = ensure(c, c->sw_prof, (size_t)grid * (CW + 1) * 4 * 8 * 2))) return rc;
+    a.prof = (unsigned long long*)c->sw_prof.p + (second ? (size_t)grid * (CW + 1) * 4 : 0);
+    c->sw_prof_n = grid * (CW + 1) * 4 * 2;
+#endif
+    if (second) hipLaunchKernelGGL((svk::k_sweep<N, true, CW>), dim3(grid), dim3(NTHR), lds, c->stream, a);
+    else hipLaunchKernelGGL((svk::k_sweep<N, false, CW>), dim3(grid), dim3(NTHR), lds, c->stream, a);
     return SV_OK;
 }
-int launch_sweep(sv_ctx* c, bool second, int nb) {
+template <int CW>
+int launch_sweep_cw(sv_ctx* c, bool second, int nb) {
     switch (c->prm.num_disparities / 32) {
-        case 1: return launch_sweep_n<1>(c, second, nb);
-        case 2: return launch_sweep_n<2>(c, second, nb);
-        case 3: return launch_sweep_n<3>(c, second, nb);
-        case 4: return launch_sweep_n<4>(c, second, nb);
+        case 1: return launch_sweep_n<1, CW>(c, second, nb);
+        case 2: return launch_sweep_n<2, CW>(c, second, nb);
+        case 3: return launch_sweep_n<3, CW>(c, second, nb);
+        case 4: return launch_sweep_n<4, CW>(c, second, nb);
         default: return fail(c, SV_ERR_UNSUPPORTED, "fused sweeps need D <= 128");
     }
+}
+int launch_sweep(sv_ctx* c, bool second, int nb) {
+    return c->sweep_cw == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
 }
 // a sweep kernel gave up waiting for its neighbour band (never expected; reported at the next sync point)
 int check_sweep_error(sv_ctx* c) {
@@ -581,6 +604,7 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     if (const char* e = getenv("SV_FUSE_WTA_MIN_BATCH")) c->fuse_wta_min_batch = atoi(e);  // tuning knobs
     if (const char* e = getenv("SV_SWEEP_MIN_BATCH")) c->sweep_min_batch = atoi(e);
     if (const char* e = getenv("SV_SWEEP_MODE")) c->sweep_mode = atoi(e);
+    if (const char* e = getenv("SV_SWEEP_CW")) c->sweep_cw = atoi(e) == 15 ? 15 : 7;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("SV_SWEEP_NCU")) c->n_cu = atoi(e) > 0 ? atoi(e) : c->n_cu;  // tests: few groups, many frames each
     HIPCHK(c, hipHostMalloc((void**)&c->sw_error, sizeof(unsigned int), hipHostMallocMapped));
@@ -598,7 +622,7 @@ int sv_destroy(sv_ctx* c) {
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->mapper_lr[0], &c->mapper_lr[1], &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt, &c->wls_lut, &c->wls_wh, &c->wls_wv, &c->wls_cur, &c->wls_tmp, &c->wls_g,
-                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink};
+                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
             for (Buf* b : all) release(*b);
             if (c->sw_error) (void)hipHostFree(c->sw_error);
             if (c->ev_ok)
@@ -954,6 +978,16 @@ int sv_synchronize(sv_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_sweep_error(c);
 }
+
+#ifdef SV_SWEEP_PROF
+// diagnostic builds only: copies the cycle sums of the last sweep launches to the host
+int sv_debug_sweep_prof(sv_ctx* c, unsigned long long* out, int n) {
+    if (!c || !out || n < c->sw_prof_n) return c ? c->sw_prof_n : -1;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(out, c->sw_prof.p, (size_t)c->sw_prof_n * 8, hipMemcpyDeviceToHost);
+    return c->sw_prof_n;
+}
+#endif
 
 int sv_set_debug(sv_ctx* c, int enable) {
     if (!c) return SV_ERR_INVALID_ARG;

@@ -36,20 +36,26 @@ constexpr int DPP_ROW_SHR1 = 0x111;  // lane i <- lane i-1
 constexpr int DPP_ROW_MIRROR = 0x140;
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
 
-// all-lanes reduction over a 16-lane row (every lane ends with the result)
+// all-lanes reduction over a 16-lane row (every lane ends with the result).  `old` is the
+// operation's identity: with it hipcc folds the DPP move into the ALU op (v_min_u32_dpp), one
+// instruction per butterfly stage instead of two.
 __device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
-    v = min(v, dpp<DPP_QUAD_XOR1>(v, v));
-    v = min(v, dpp<DPP_QUAD_XOR2>(v, v));
-    v = min(v, dpp<DPP_ROW_HALF_MIRROR>(v, v));
-    v = min(v, dpp<DPP_ROW_MIRROR>(v, v));
+    v = min(v, dpp<DPP_QUAD_XOR1>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_QUAD_XOR2>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_ROW_HALF_MIRROR>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_ROW_MIRROR>(0xFFFFFFFFu, v));
     return v;
 }
 __device__ __forceinline__ uint32_t row16_or_u32(uint32_t v) {
-    v |= dpp<DPP_QUAD_XOR1>(v, v);
-    v |= dpp<DPP_QUAD_XOR2>(v, v);
-    v |= dpp<DPP_ROW_HALF_MIRROR>(v, v);
-    v |= dpp<DPP_ROW_MIRROR>(v, v);
+    v |= dpp<DPP_QUAD_XOR1>(0u, v);
+    v |= dpp<DPP_QUAD_XOR2>(0u, v);
+    v |= dpp<DPP_ROW_HALF_MIRROR>(0u, v);
+    v |= dpp<DPP_ROW_MIRROR>(0u, v);
     return v;
+}
+// saturating packed add (v_pk_add_u16 clamp): each half = min(a + b, 65535)
+__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
 
 template <int N>

@@ -26,8 +26,7 @@
 
 namespace svk {
 
-constexpr int SW_ROWS = 60;   // image rows per band = compute lane-groups per workgroup (15 waves x 4)
-constexpr int SW_RING = 32;   // pixels in the import / export rings
+constexpr int SW_RING = 16;   // pixels in the import / export rings
 constexpr int SW_LEAD = 32;   // loop steps before stream pixel 0 (service pipeline warm-up), multiple of 4
 constexpr int SW_DEPTH = 4;   // global-load pipeline depth in steps
 constexpr int SW_SPIN_MAX = 1 << 18;
@@ -39,19 +38,22 @@ struct SweepArgs {
     unsigned long long* handoff;   // [n_groups][n_bands - 1][ho_px + 1][REC / 2]: band-boundary records (+1 dummy)
     unsigned int* progress;        // [n_groups][n_bands]: stream pixels exported so far (zeroed before the launch)
     unsigned int* error;           // host-visible: set when a bounded wait ran out
-    uint32_t* sink;                // [gridDim.x * 1024 * 4] u32: target of the stores of inactive steps
+    uint32_t* sink;                // [gridDim.x * blockDim.x * 4] u32: target of the stores of inactive steps
     int W1, H, W;
     uint32_t P1P1, P2P2;
     int uniq;
     int n_frames, n_groups, n_bands;
+    int fpg;                       // frames per group (the last group may hold fewer)
     int ho_px;                     // handoff pixels per (group, band): frames-per-group * W1, rounded up
+    unsigned long long* prof;      // diagnostic builds (-DSV_SWEEP_PROF): [gridDim.x][waves][4] cycle sums, else unused
 };
 
 template <int N>
 __host__ __device__ constexpr int sweep_rec_words() { return 3 * 16 * N + 16; }
-template <int N>
+// CW = compute waves per workgroup (4 image rows each) + one service wave
+template <int N, int CW>
 __host__ __device__ constexpr size_t sweep_lds_bytes() {
-    return sizeof(uint32_t) * ((size_t)(2 * (SW_ROWS + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4);
+    return sizeof(uint32_t) * ((size_t)(2 * (4 * CW + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4);
 }
 
 // One SGM path update of one pixel: Lp = previous L along the path (0 and delta = P2 when the path
@@ -84,63 +86,91 @@ __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_
     dd_out = mn + P2P2;
 }
 
+#ifdef SV_SWEEP_PROF
+// Diagnostic build only: s_memtime stamps around the phases of a step (MI355X_MICROARCH.md, DVFS
+// give-back item 6: never quote this build's run time, read its shares).
+#define SW_STAMP(v)                                   \
+    __builtin_amdgcn_sched_barrier(0);                \
+    unsigned long long v;                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+#define SW_PROF(...) __VA_ARGS__
+#else
+#define SW_STAMP(v)
+#define SW_PROF(...)
+#endif
+
 __device__ __forceinline__ void sweep_barrier() {
     // LDS traffic of this wave done, then the workgroup barrier.  Not __syncthreads(): that would
     // also drain vmcnt and with it the global-load pipeline.
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int N, bool SECOND>
-__global__ __launch_bounds__(1024) void k_sweep(SweepArgs a) {
+template <int N, bool SECOND, int CW>
+__global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
+    constexpr int SW_ROWS = 4 * CW, NTHR = (CW + 1) * 64;
     constexpr int PXW = 16 * N, REC = sweep_rec_words<N>(), RECQ = REC / 2;
     extern __shared__ __align__(16) uint32_t sw_lds[];
     uint32_t* const slot = sw_lds;                              // [2][SW_ROWS + 1][REC]: slot[p][r] is read by row r
     uint32_t* const imp = slot + 2 * (SW_ROWS + 1) * REC;       // [SW_RING][REC]: records of the previous band's last row
     uint32_t* const expo = imp + SW_RING * REC;                 // [SW_RING][REC]: records of this band's last row
-    volatile uint32_t* const ctrl = expo + SW_RING * REC;       // [0]: abort
+    uint32_t* const abortp = expo + SW_RING * REC;              // [0]: set by the service wave when a bounded wait ran out
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane & 15;
     const int band = blockIdx.x % a.n_bands, group = blockIdx.x / a.n_bands;
-    const int nfr = (a.n_frames - group + a.n_groups - 1) / a.n_groups;  // frames of this group: group, group + n_groups, ...
+    const int f0 = group * a.fpg;                          // this group's frames: f0 .. f0 + nfr - 1 (a contiguous block)
+    const int nfr = min(a.fpg, a.n_frames - f0);
     const int W1 = a.W1, H = a.H;
     const int total_px = nfr * W1;  // length of the pixel stream of every row of this group
-    const bool compute = wave < 15;
+    const bool compute = wave < CW;
     const int r = compute ? wave * 4 + (lane >> 4) : 0;  // local row
     const int yl = band * SW_ROWS + r;                    // row in sweep order
     const bool rowok = compute && yl < H;
     const int yp = SECOND ? H - 1 - min(yl, H - 1) : min(yl, H - 1);  // image row
-    const size_t frame_words = (size_t)H * W1 * PXW;
+    // Addresses: 32-bit word offsets from the group's first frame (the host keeps a group's block of
+    // C below 4 GiB), so a load is one saddr + voffset instruction and a step costs a few VALU ops.
+    const uint32_t frame_words = (uint32_t)H * W1 * PXW;
+    const uint32_t* const Cg = a.C + (size_t)f0 * frame_words;
+    uint32_t* const Sg = a.S + (size_t)f0 * frame_words;
+    uint2* const recg = a.rec + (size_t)f0 * H * a.W;
+    const uint32_t rowoff = (uint32_t)yp * W1 * PXW + q * N;
     const uint32_t P1P1 = a.P1P1, P2P2 = a.P2P2;
-    uint32_t* const mysink = a.sink + ((size_t)blockIdx.x * 1024 + tid) * 4;
 
-    if (tid == 0) ctrl[0] = 0;
+    if (tid == 0) (*abortp) = 0;
+    // Band 0 has no row above: its import ring is never written, so fill it once with the record
+    // of a path start (L = 0, delta = P2) and the first image row needs no special case.
+    if (band == 0)
+        for (int i = tid; i < SW_RING * REC; i += NTHR) imp[i] = (i % REC) >= 3 * PXW ? P2P2 : 0u;
     __syncthreads();
 
-    // ---- compute rows: cursors.  x < 0 until the row's turn comes; fi counts frames of the group.
-    int x = -SW_LEAD - 2 * r - 2, fi = 0;            // compute cursor at step tau = -SW_LEAD
-    int lx = x, lfi = 0;                             // load cursor, SW_DEPTH steps ahead after the prologue
+    // ---- compute rows.  The load cursor (lx, lfi, lfbase) runs SW_DEPTH steps ahead of the compute
+    // cursor x; the offset and the validity of a pixel are computed once, at load time, and queued.
+    int x = -SW_LEAD - 2 * r - 2;                    // compute cursor at step tau = -SW_LEAD (x < 0: not started)
+    int lx = x, lfi = 0;
+    uint32_t lfbase = 0;                             // word offset of frame lfi
     uint32_t r0[N], d1n[N], d1r[N], d2r[N];          // own horizontal L; delayed records of the row above
     uint32_t dd0 = P2P2, d1n_dd = P2P2, d1r_dd = P2P2, d2r_dd = P2P2;
 #pragma unroll
     for (int k = 0; k < N; k++) r0[k] = d1n[k] = d1r[k] = d2r[k] = 0;
-    uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N];
+    uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH], recq[SW_DEPTH];
+    uint32_t lrbase = 0;                             // index of frame lfi's first WTA record
+    const uint32_t rowrec = (uint32_t)yp * a.W + 32 * N, frame_px = (uint32_t)H * a.W;
+    bool actq[SW_DEPTH];
 
-    auto advance = [&](int& cx, int& cfi) {
-        cx++;
-        const bool wrap = cx == W1;
-        cx = wrap ? 0 : cx;
-        cfi += wrap ? 1 : 0;
-    };
-    auto pixel_words = [&](int cx, int cfi) -> size_t {  // word offset of (frame, row, x) for this lane, clamped to a valid pixel
-        const int xx = min(max(cx, 0), W1 - 1), ff = min(cfi, nfr - 1);
-        const int xp = SECOND ? W1 - 1 - xx : xx;
-        return (size_t)(group + ff * a.n_groups) * frame_words + ((size_t)yp * W1 + xp) * PXW + q * N;
-    };
-    auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N]) {
-        const size_t off = pixel_words(lx, lfi);
-        load_regs<N>(a.C + off, c);
-        if (SECOND) load_regs<N>(a.S + off, s);
-        advance(lx, lfi);
+    auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N], uint32_t& off, uint32_t& rq, bool& act) {
+        const int xx = min(max(lx, 0), W1 - 1);      // clamped: a load outside the stream reads a valid, unused pixel
+        const uint32_t xp = (uint32_t)(SECOND ? W1 - 1 - xx : xx);
+        off = lfbase + rowoff + xp * PXW;
+        rq = lrbase + rowrec + xp;
+        act = rowok && lx >= 0 && lfi < nfr;
+        load_regs<N>(Cg + off, c);
+        if (SECOND) load_regs<N>(Sg + off, s);
+        lx++;
+        const bool wrap = lx == W1;
+        lx = wrap ? 0 : lx;
+        lfi += wrap ? 1 : 0;
+        lfbase += (wrap && lfi < nfr) ? frame_words : 0u;
+        if (SECOND) lrbase += (wrap && lfi < nfr) ? frame_px : 0u;
     };
 
     // ---- service wave state
@@ -160,14 +190,15 @@ __global__ __launch_bounds__(1024) void k_sweep(SweepArgs a) {
     // service wave never share a basic block, so each body is straight-line code for the scheduler.
     if (compute) {
 #pragma unroll
-        for (int j = 0; j < SW_DEPTH; j++) issue(cb[j], sb[j]);
-        const bool y0 = yl == 0;
+        for (int j = 0; j < SW_DEPTH; j++) issue(cb[j], sb[j], offq[j], recq[j], actq[j]);
+        SW_PROF(unsigned long long pacc[4] = {0, 0, 0, 0};)
         for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
-            if (ctrl[0] != 0) break;
+            if ((*abortp) != 0) break;
 #pragma unroll
             for (int j = 0; j < SW_DEPTH; j++) {
+                SW_STAMP(T0)
                 const int u = tau + j - 2 * r - 2;  // stream pixel of this row at this step; (tau + j) & 1 == j & 1
-                const bool active = rowok && x >= 0 && fi < nfr;
+                const bool active = actq[j];
                 // record of the row above: pixel u + 1 of its stream
                 const uint32_t* src = (r == 0) ? imp + ((u + 1) & (SW_RING - 1)) * REC
                                                : slot + (((j + 1) & 1) * (SW_ROWS + 1) + r) * REC;
@@ -176,11 +207,13 @@ __global__ __launch_bounds__(1024) void k_sweep(SweepArgs a) {
                 load_regs<N>(src + PXW + q * N, in_dn);
                 load_regs<N>(src + 2 * PXW + q * N, in_dr);
                 const uint32_t dd_dl = src[3 * PXW], dd_dn = src[3 * PXW + 1], dd_dr = src[3 * PXW + 2];
+                SW_STAMP(T1)
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
                 sweep_path<N>(cb[j], r0, dd0, x == 0, P1P1, P2P2, L0, n0);                   // horizontal
-                sweep_path<N>(cb[j], d2r, d2r_dd, y0 || x == 0, P1P1, P2P2, L1, n1);        // from (x-1, y-1)
-                sweep_path<N>(cb[j], d1n, d1n_dd, y0, P1P1, P2P2, L2, n2);                  // from (x,   y-1)
-                sweep_path<N>(cb[j], in_dl, dd_dl, y0 || x == W1 - 1, P1P1, P2P2, L3, n3);  // from (x+1, y-1)
+                sweep_path<N>(cb[j], d2r, d2r_dd, x == 0, P1P1, P2P2, L1, n1);               // from (x-1, y-1)
+                sweep_path<N>(cb[j], d1n, d1n_dd, false, P1P1, P2P2, L2, n2);                  // from (x,   y-1)
+                sweep_path<N>(cb[j], in_dl, dd_dl, x == W1 - 1, P1P1, P2P2, L3, n3);  // from (x+1, y-1)
+                SW_STAMP(T2)
                 // own record for the row below
                 uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
                                                    : slot + ((j & 1) * (SW_ROWS + 1) + r + 1) * REC;
@@ -191,10 +224,11 @@ __global__ __launch_bounds__(1024) void k_sweep(SweepArgs a) {
                 uint32_t snew[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) {
-                    const uint32_t s01 = pk_min(pk_add(L0[k], L1[k]), 0x7FFF7FFFu);
-                    const uint32_t s23 = pk_min(pk_add(L2[k], L3[k]), 0x7FFF7FFFu);
-                    const uint32_t s4 = pk_min(pk_add(s01, s23), 0x7FFF7FFFu);
-                    snew[k] = SECOND ? pk_min(pk_add(sb[j][k], s4), 0x7FFF7FFFu) : s4;
+                    // every L <= 32767, so the pair sums cannot wrap; the rest saturates at 65535 and
+                    // is clamped once: min(S + L, 32767) applied path by path gives the same value
+                    uint32_t s4 = pk_add_sat(pk_add(L0[k], L1[k]), pk_add(L2[k], L3[k]));
+                    if (SECOND) s4 = pk_add_sat(s4, sb[j][k]);
+                    snew[k] = pk_min(s4, 0x7FFF7FFFu);
                     r0[k] = L0[k];
                     d2r[k] = d1r[k];
                     d1r[k] = in_dr[k];
@@ -206,26 +240,29 @@ __global__ __launch_bounds__(1024) void k_sweep(SweepArgs a) {
                 d1n_dd = dd_dn;
                 if (SECOND) {
                     const uint2 w = wta_record<N>(snew, q, a.uniq);  // all 16 lanes hold the same record
-                    const int xp = W1 - 1 - min(max(x, 0), W1 - 1);
-                    uint2* o = active ? a.rec + ((size_t)(group + min(fi, nfr - 1) * a.n_groups) * H + yp) * a.W + xp + 32 * N
-                                      : reinterpret_cast<uint2*>(mysink);
-                    *o = w;
+                    if (active) recg[recq[j]] = w;
                 } else {
-                    uint32_t* o = active ? a.S + pixel_words(x, fi) : mysink;
-                    store_regs<N>(o, snew);
+                    if (active) store_regs<N>(Sg + offq[j], snew);
                 }
-                advance(x, fi);
-                issue(cb[j], sb[j]);
+                x++;
+                x = x == W1 ? 0 : x;
+                issue(cb[j], sb[j], offq[j], recq[j], actq[j]);
+                SW_STAMP(T3)
                 sweep_barrier();
+                SW_STAMP(T4)
+                SW_PROF(pacc[0] += T1 - T0; pacc[1] += T2 - T1; pacc[2] += T3 - T2; pacc[3] += T4 - T3;)
             }
         }
+        SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
     } else {
         bool aborted = false;
+        SW_PROF(unsigned long long pacc[4] = {0, 0, 0, 0};)
         for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
-            if (ctrl[0] != 0) { aborted = true; break; }
+            if ((*abortp) != 0) { aborted = true; break; }
 #pragma unroll
             for (int j = 0; j < SW_DEPTH; j++) {
                 const int t = tau + j;
+                SW_STAMP(T0)
                 // import: pixel t + 2 of the previous band's last row (loaded four steps ago) -> ring;
                 // row 0 reads pixel t' - 1 at step t'.
                 if (do_import) {
@@ -235,7 +272,7 @@ __global__ __launch_bounds__(1024) void k_sweep(SweepArgs a) {
                         while (__hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                             __builtin_amdgcn_s_sleep(16);
                             if (++spins > SW_SPIN_MAX) {
-                                ctrl[0] = 1;
+                                (*abortp) = 1;
                                 if (lane == 0) __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 break;
                             }
@@ -263,9 +300,13 @@ __global__ __launch_bounds__(1024) void k_sweep(SweepArgs a) {
                         if (lane == 0) __hip_atomic_store(flag_out, (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+                SW_STAMP(T3)
                 sweep_barrier();
+                SW_STAMP(T4)
+                SW_PROF(pacc[0] += T3 - T0; pacc[3] += T4 - T3;)
             }
         }
+        SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
         if (do_export && !aborted) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(flag_out, (unsigned)total_px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

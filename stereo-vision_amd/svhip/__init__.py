@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libsv_hip.so")
+LIB_PATH = os.environ.get("SVHIP_LIB") or os.path.join(os.path.dirname(_HERE), "libsv_hip.so")  # SVHIP_LIB: diagnostic builds
 
 INVALID = -16
 PATH_R, PATH_DR, PATH_D, PATH_DL, PATH_L, PATH_UL, PATH_U, PATH_UR = (1 << i for i in range(8))
