@@ -362,36 +362,72 @@ __global__ __launch_bounds__(256) void k_cost_col0(uint32_t* __restrict__ C, int
 // S[best-1], S[best], S[best+1] with C integer division.  Returns the 8-byte WTA record
 // {disp16, raw d (-1 = none), minS, 0}; every lane of the group gets the same record.
 // ---------------------------------------------------------------------------------------------
+// The uniqueness test "S[d]*(100-uniq) < minS*100" is done as S[d] < T with
+// T = ceil(minS*100 / (100-uniq)), the division by the (uniform) constant through a magic multiply.
+struct UniqK {
+    int mul;         // 100 - uniquenessRatio
+    uint32_t magic;  // floor(2^32 / mul) + 1 (exact for numerators < 2^22), unused when mul == 0
+};
+__device__ __forceinline__ UniqK make_uniq(int uniq) {
+    UniqK u;
+    u.mul = 100 - uniq;
+    u.magic = u.mul > 0 ? 0xFFFFFFFFu / (uint32_t)u.mul + 1u : 0u;
+    return u;
+}
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {  // each half = max(a - b, 0)
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+
 template <int N>
-__device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, int uniq) {
+__device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK uq) {
     constexpr int D = 32 * N;
     const int dbase = q * 2 * N;
+    // first minimum: packed key (S << 16 | d) under a 32-bit min
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        key = min(key, ((s[k] & 0xFFFFu) << 16) | (uint32_t)(dbase + 2 * k));
+        key = min(key, (s[k] << 16) | (uint32_t)(dbase + 2 * k));
         key = min(key, (s[k] & 0xFFFF0000u) | (uint32_t)(dbase + 2 * k + 1));
     }
     key = row16_min_u32(key);
     const int minS = (int)(key >> 16), best = (int)(key & 0xFFFFu);
-    uint32_t bad = 0, nb = 0;
-    const int thr = minS * 100, mul = 100 - uniq;
+    // uniqueness: the smallest S outside best-1..best+1 must not be below T
+    const uint32_t thr = (uint32_t)minS * 100u;
+    const uint32_t T = uq.mul > 0 ? __umulhi(thr + (uint32_t)uq.mul - 1u, uq.magic) : (thr > 0u ? 0x10000u : 0u);
+    const int p = best - 1 - dbase;  // position of best-1 in this lane's 2N values (may lie outside)
+    const uint32_t sh = (uint32_t)(p + 2);
+    const uint32_t bm = sh < 32u ? ((7u << sh) >> 2) : 0u;  // bit i set: position i is one of best-1, best, best+1
+    uint32_t m2 = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int d = dbase + 2 * k + h;
-            const int v = (int)(h ? (s[k] >> 16) : (s[k] & 0xFFFFu));
-            bad |= (v * mul < thr && abs(best - d) > 1) ? 1u : 0u;
-            nb |= (d == best - 1) ? ((uint32_t)v << 16) : 0u;
-            nb |= (d == best + 1) ? (uint32_t)v : 0u;
-        }
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)bm, 2 * k, 1);      // 0 or 0xFFFFFFFF
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bm, 2 * k + 1, 1);
+        const uint32_t excl = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
+        m2 = pk_min(m2, s[k] | excl);
     }
-    bad = row16_or_u32(bad);
+    m2 = pk_min(m2, __builtin_amdgcn_alignbit(m2, m2, 16));
+    m2 = row16_min_u32(m2 & 0xFFFFu);
+    const bool bad = m2 < T;
+    // S[best-1] and S[best+1]: positions p and p+2 of the owning lane, 0 elsewhere, OR-reduced
+    auto pick = [&](int pos) -> uint32_t {
+        uint32_t v = s[0];
+#pragma unroll
+        for (int k = 1; k < N; k++) v = (pos >> 1) == k ? s[k] : v;
+        v = (pos & 1) ? (v >> 16) : (v & 0xFFFFu);
+        return (uint32_t)pos < (uint32_t)(2 * N) ? v : 0u;
+    };
+    uint32_t nb = (pick(p) << 16) | pick(p + 2);
     nb = row16_or_u32(nb);
     const int sm = (int)(nb >> 16), sp = (int)(nb & 0xFFFFu);
-    const int denom2 = max(sm + sp - 2 * minS, 1);
-    const int sub = (0 < best && best < D - 1) ? ((sm - sp) * 16 + denom2) / (denom2 * 2) : 0;
+    // sub-pixel: ((sm - sp)*16 + den) / (2*den), C division (truncation).  |quotient| <= 8, operands
+    // exact in float: a float estimate, then an exact integer correction of +-1.
+    const int den = max(sm + sp - 2 * minS, 1), num = (sm - sp) * 16 + den, den2 = den * 2;
+    int sub = (int)((float)num * __builtin_amdgcn_rcpf((float)den2));  // truncates toward zero
+    int rem = num - sub * den2;
+    // the remainder of a truncating division has the sign of num and magnitude < den2
+    if (rem >= den2 || (num < 0 && rem > 0)) { sub++; rem -= den2; }
+    if (rem <= -den2 || (num >= 0 && rem < 0)) { sub--; rem += den2; }
+    sub = (0 < best && best < D - 1) ? sub : 0;
     const bool ok = minS < 32767 && !bad;  // minS == 32767: every S saturated, no minimum
     const int dv = ok ? best * 16 + sub : -16, rw = ok ? best : -1;
     return make_uint2(((uint32_t)dv & 0xFFFFu) | ((uint32_t)rw << 16), (uint32_t)minS);
@@ -437,6 +473,7 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
     C += (size_t)blockIdx.y * H * W1 * pxN;  // frame of a batched launch
     S += (size_t)blockIdx.y * H * W1 * pxN;
     if (LAST) rec += (size_t)blockIdx.y * H * W;
+    const UniqK uqk = make_uniq(uniq);
 
     // load cursor (runs one batch ahead of the compute)
     int lx, ly;
@@ -489,9 +526,9 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
         uint32_t snew[N];
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            uint32_t t = pk_add(pk_min(m[k], m[k + 1]), P1P1);
-            t = pk_min(pk_min(t, r[k]), dd);
-            uint32_t L = pk_sub(pk_add(c[k], t), dd);
+            // C + min(a, dd) - dd  ==  C - max(dd - a, 0): one saturating subtract
+            const uint32_t t = pk_min(pk_add(pk_min(m[k], m[k + 1]), P1P1), r[k]);
+            uint32_t L = pk_sub(c[k], pk_sub_sat(dd, t));
             r[k] = L;
             mn = pk_min(mn, L);
             snew[k] = FIRST ? L : pk_min(pk_add(s[k], L), 0x7FFF7FFFu);
@@ -499,7 +536,7 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
         mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // both halves = lane minimum
         mn = row16_min_u32(mn);
         dd = mn + P2P2;  // halves cannot carry: min + P2 < 65536
-        if (LAST) rec[px] = wta_record<N>(snew, q, uniq);  // all 16 lanes store the same record
+        if (LAST) rec[px] = wta_record<N>(snew, q, uqk);  // all 16 lanes store the same record
         else store_regs<N>(S + off, snew);
     };
 
@@ -566,7 +603,7 @@ __global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, uin
     S += (size_t)blockIdx.y * H * W1 * 16 * N;
     uint32_t s[N];
     load_regs<N>(S + ((size_t)y * W1 + xl) * 16 * N + q * N, s);
-    uint2 r = wta_record<N>(s, q, uniq);
+    uint2 r = wta_record<N>(s, q, make_uniq(uniq));
     if (x < D) r = make_uint2(0xFFFFFFF0u, 32767u);  // {-16, -1, 32767}
     rec[(size_t)blockIdx.y * npx + p] = r;
 }

@@ -56,16 +56,12 @@ __host__ __device__ constexpr size_t sweep_lds_bytes() {
     return sizeof(uint32_t) * ((size_t)(2 * (4 * CW + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4);
 }
 
-// One SGM path update of one pixel: Lp = previous L along the path (0 and delta = P2 when the path
-// starts here), c = the pixel's costs.  Same arithmetic as k_agg's step.
+// One SGM path update of one pixel: r = previous L along the path (0 with dd = P2 when the path
+// starts here), c = the pixel's costs.  Same arithmetic as k_agg's step:
+//   L = C + min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1, dd) - dd  =  C - max(dd - a, 0).
 template <int N>
-__device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&lp_in)[N], uint32_t dd_in, bool fresh,
-                                           uint32_t P1P1, uint32_t P2P2, uint32_t (&L)[N], uint32_t& dd_out) {
-    const uint32_t keep = fresh ? 0u : 0xFFFFFFFFu;
-    const uint32_t dd = fresh ? P2P2 : dd_in;
-    uint32_t r[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) r[k] = lp_in[k] & keep;
+__device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&r)[N], uint32_t dd, uint32_t P1P1,
+                                           uint32_t P2P2, uint32_t (&L)[N], uint32_t& dd_out) {
     const uint32_t prevHi = dpp<DPP_ROW_SHR1>(0x7FFF7FFFu, r[N - 1]);
     const uint32_t nextLo = dpp<DPP_ROW_SHL1>(0x7FFF7FFFu, r[0]);
     uint32_t m[N + 1];
@@ -76,9 +72,8 @@ __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_
     uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        uint32_t t = pk_add(pk_min(m[k], m[k + 1]), P1P1);
-        t = pk_min(pk_min(t, r[k]), dd);
-        L[k] = pk_sub(pk_add(c[k], t), dd);
+        const uint32_t t = pk_min(pk_add(pk_min(m[k], m[k + 1]), P1P1), r[k]);
+        L[k] = pk_sub(c[k], pk_sub_sat(dd, t));
         mn = pk_min(mn, L[k]);
     }
     mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));
@@ -148,10 +143,13 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     int x = -SW_LEAD - 2 * r - 2;                    // compute cursor at step tau = -SW_LEAD (x < 0: not started)
     int lx = x, lfi = 0;
     uint32_t lfbase = 0;                             // word offset of frame lfi
-    uint32_t r0[N], d1n[N], d1r[N], d2r[N];          // own horizontal L; delayed records of the row above
-    uint32_t dd0 = P2P2, d1n_dd = P2P2, d1r_dd = P2P2, d2r_dd = P2P2;
+    // own horizontal L; records of the row above waiting for their turn: the "down" part is used one
+    // step after it was read, the "down-right" part two steps after (two registers sets, alternating)
+    uint32_t r0[N], dn[N], dr[2][N];
+    uint32_t dd0 = P2P2, dn_dd = P2P2, dr_dd[2] = {P2P2, P2P2};
 #pragma unroll
-    for (int k = 0; k < N; k++) r0[k] = d1n[k] = d1r[k] = d2r[k] = 0;
+    for (int k = 0; k < N; k++) r0[k] = dn[k] = dr[0][k] = dr[1][k] = 0;
+    const UniqK uqk = make_uniq(a.uniq);
     uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH], recq[SW_DEPTH];
     uint32_t lrbase = 0;                             // index of frame lfi's first WTA record
     const uint32_t rowrec = (uint32_t)yp * a.W + 32 * N, frame_px = (uint32_t)H * a.W;
@@ -202,17 +200,31 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 // record of the row above: pixel u + 1 of its stream
                 const uint32_t* src = (r == 0) ? imp + ((u + 1) & (SW_RING - 1)) * REC
                                                : slot + (((j + 1) & 1) * (SW_ROWS + 1) + r) * REC;
-                uint32_t in_dl[N], in_dn[N], in_dr[N];
+                uint32_t in_dl[N];
                 load_regs<N>(src + q * N, in_dl);
-                load_regs<N>(src + PXW + q * N, in_dn);
-                load_regs<N>(src + 2 * PXW + q * N, in_dr);
-                const uint32_t dd_dl = src[3 * PXW], dd_dn = src[3 * PXW + 1], dd_dr = src[3 * PXW + 2];
+                uint32_t dd_dl = src[3 * PXW];
                 SW_STAMP(T1)
+                // Path starts (x == 0: horizontal and down-right; x == W1-1: down-left) come up once per
+                // row and frame, so the reset sits behind a wave-uniform branch instead of in every step.
+                const bool st_l = x == 0, st_r = x == W1 - 1;
+                if (__builtin_amdgcn_ballot_w64(st_l || st_r) != 0) {
+                    const uint32_t kl = st_l ? 0u : 0xFFFFFFFFu, kr = st_r ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = 0; k < N; k++) { r0[k] &= kl; dr[j & 1][k] &= kl; in_dl[k] &= kr; }
+                    dd0 = st_l ? P2P2 : dd0;
+                    dr_dd[j & 1] = st_l ? P2P2 : dr_dd[j & 1];
+                    dd_dl = st_r ? P2P2 : dd_dl;
+                }
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
-                sweep_path<N>(cb[j], r0, dd0, x == 0, P1P1, P2P2, L0, n0);                   // horizontal
-                sweep_path<N>(cb[j], d2r, d2r_dd, x == 0, P1P1, P2P2, L1, n1);               // from (x-1, y-1)
-                sweep_path<N>(cb[j], d1n, d1n_dd, false, P1P1, P2P2, L2, n2);                  // from (x,   y-1)
-                sweep_path<N>(cb[j], in_dl, dd_dl, x == W1 - 1, P1P1, P2P2, L3, n3);  // from (x+1, y-1)
+                sweep_path<N>(cb[j], r0, dd0, P1P1, P2P2, L0, n0);                   // horizontal
+                sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, P2P2, L1, n1);   // from (x-1, y-1): read two steps ago
+                sweep_path<N>(cb[j], dn, dn_dd, P1P1, P2P2, L2, n2);                 // from (x,   y-1): read last step
+                sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, P2P2, L3, n3);              // from (x+1, y-1): read now
+                // the parts of this step's record that are used later go straight into their registers
+                load_regs<N>(src + PXW + q * N, dn);
+                load_regs<N>(src + 2 * PXW + q * N, dr[j & 1]);
+                dn_dd = src[3 * PXW + 1];
+                dr_dd[j & 1] = src[3 * PXW + 2];
                 SW_STAMP(T2)
                 // own record for the row below
                 uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
@@ -230,16 +242,10 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     if (SECOND) s4 = pk_add_sat(s4, sb[j][k]);
                     snew[k] = pk_min(s4, 0x7FFF7FFFu);
                     r0[k] = L0[k];
-                    d2r[k] = d1r[k];
-                    d1r[k] = in_dr[k];
-                    d1n[k] = in_dn[k];
                 }
                 dd0 = n0;
-                d2r_dd = d1r_dd;
-                d1r_dd = dd_dr;
-                d1n_dd = dd_dn;
                 if (SECOND) {
-                    const uint2 w = wta_record<N>(snew, q, a.uniq);  // all 16 lanes hold the same record
+                    const uint2 w = wta_record<N>(snew, q, uqk);  // all 16 lanes hold the same record
                     if (active) recg[recq[j]] = w;
                 } else {
                     if (active) store_regs<N>(Sg + offq[j], snew);
