@@ -10,10 +10,13 @@ A "step" is one pass of the hot path (prefilter -> cost volume -> 8-path SGM -> 
 median; sv_compute_gray_batch_dev) over one batch of synthetic stereo pairs that are already
 resident in HBM.  value = frames of all ranks / max-over-ranks wall time of exactly K steps.
 
-roofline: the dominant kernel is svk::k_agg (one SGM path over the whole batch per launch).  Its
+roofline: the dominant kernel is the aggregation kernel: svk::k_sweep (four SGM paths of a sweep over
+the whole batch per launch; large batches, D <= 128) or svk::k_agg (one path per launch).  Its
 average launch duration is measured live with HIP events recorded by libsv_hip on the stream the
-kernels run on, over the K timed steps; achieved = algorithmic bytes per launch (3 * V * batch,
-V = (W-D)*H*D*2) / that duration.
+kernels run on, over the K timed steps; achieved = algorithmic bytes per launch (3 * V * batch per
+path, V = (W-D)*H*D*2, SURVEY.md 8(d): 12 * V * batch for a four-path sweep) / that duration.  The
+fused sweep moves far fewer bytes than that (traffic = the PMC figure), so its algorithmic rate can
+exceed the HBM peak; hbm_actual_gbs = traffic / duration is what the memory system really carries.
 
 cpu_baseline: the CPU oracle (oracle/libsv_ref.so, a restatement = "port"; OpenCV is not
 installed) timed single-threaded on rank 0 on a bounded sample of the same workload.
@@ -76,13 +79,13 @@ def cpu_baseline(W, H, D, paths, left, right, budget_s=12.0):
     return out
 
 
-def pmc_traffic(config, batch):
-    """HBM bytes per k_agg launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+def pmc_traffic(config, batch, kernel):
+    """HBM bytes per aggregation launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this workload, gfx950 FETCH_SIZE x2 correction applied);
-    None when no pass was collected for this config/batch."""
+    None when no pass was collected for this config/batch/kernel."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f).get("%s_b%d" % (config, batch))
+            t = json.load(f).get("%s_b%d%s" % (config, batch, "_sweep" if kernel == "svk::k_sweep" else ""))
         return int(t["traffic_bytes_per_launch"]) if t else None
     except (OSError, ValueError, KeyError):
         return None
@@ -93,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step per GPU (C2: 256 pairs = 34 GB of HBM)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -120,7 +123,7 @@ def main():
     from svhip import synth
 
     W, H, D, paths = CONFIGS[args.config]
-    B = args.batch if args.config != "c4" else min(args.batch, 4)
+    B = args.batch if args.config != "c4" else min(args.batch, 4)   # C4: 1.84 GB of volumes per pair
     params = svhip.default_params(D, paths)  # SAD 7, P1 8*49, P2 32*49, cap 63, uniq 15, LR check on
     n_distinct = min(B, 8)
     seed0 = 202 if world == 1 else 500 + 16 * rank
@@ -168,9 +171,13 @@ def main():
         fps = frames / elapsed
         V = (W - D) * H * D * 2
         n_paths = bin(params.path_mask).count("1")
-        launch_s = stage_ms["aggregation"] * 1e-3 / n_paths          # mean duration of one k_agg launch
-        agg_bytes_per_launch = 3 * V * B                              # read C, read+write S, all frames of the batch
+        n_launch, n_sweeps = m.last_aggregation()
+        kernel = "svk::k_sweep" if n_sweeps == n_launch and n_sweeps > 0 else "svk::k_agg"
+        launch_s = stage_ms["aggregation"] * 1e-3 / n_launch          # mean duration of one aggregation launch
+        # algorithmic bytes: every path reads C and reads+writes S, all frames of the batch
+        agg_bytes_per_launch = 3 * V * B * n_paths // n_launch
         achieved = agg_bytes_per_launch / launch_s / 1e9
+        traffic = pmc_traffic(args.config, B, kernel)
         frame_bytes = m.algorithmic_bytes(4)
         res = {
             "metric": "disparity frames/sec per GPU at 640x480, D=128, 8 paths; % HBM roofline",
@@ -184,9 +191,11 @@ def main():
             "per_gpu_fps": round(fps / world, 2),
             "frame_roofline_frac": round(frame_bytes * (fps / world) / (HBM_PEAK_GBS * 1e9), 4),
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "svk::k_agg", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, B),
-                         "launch_us": round(launch_s * 1e6, 2), "bytes_per_launch": agg_bytes_per_launch},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "launch_us": round(launch_s * 1e6, 2), "bytes_per_launch": agg_bytes_per_launch,
+                         "paths_per_launch": n_paths // n_launch,
+                         "hbm_actual_gbs": round(traffic / launch_s / 1e9, 1) if traffic else None},
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, H, D, paths, lefts, rights)

@@ -250,8 +250,10 @@ int sv_depth_dev(sv_ctx* ctx, const int16_t* disp16_dev, const float* mapper_dev
  * debug mode.  sv_set_debug modes: 0 = production (batches of >= 6 frames fuse
  * WTA into the last path, which then keeps the finished S in registers and
  * never stores it; smaller batches, being latency-bound, run WTA as its own
- * kernel; batches of >= 8 frames with D <= 128 and all four paths of a sweep
- * enabled run the fused sweep kernels, four paths per pass over C),
+ * kernel; batches large enough to stream more than one frame through every
+ * workgroup pipeline - about 48 frames at 640x480 on 256 CUs - with D <= 128
+ * and all four paths of a sweep enabled run the fused sweep kernels, four paths
+ * per pass over C),
  * 1 = debug (per-path kernels, S always materialised), 2 = WTA fused into the
  * last path whatever the batch size, 3 = fused sweeps whatever the batch size,
  * 4 = never the fused sweeps (2-4 let tests exercise each variant on one frame). */
@@ -271,6 +273,11 @@ int sv_debug_read_plane_host(sv_ctx* ctx, int which, int16_t* plane_host);
 #define SV_N_TIMINGS 6
 int sv_enable_timing(sv_ctx* ctx, int enable);
 int sv_get_timings(sv_ctx* ctx, float* ms, int n);
+
+/* How the last sv_compute_* call aggregated: kernel launches of the aggregation
+ * stage, and how many of them were fused four-path sweeps (the rest are
+ * single-path launches).  For profiling / bench.py; no reference counterpart. */
+int sv_last_aggregation(const sv_ctx* ctx, int* n_launches, int* n_fused_sweeps);
 
 /* Algorithmic bytes per frame of the current geometry:
  * which: 0 cost, 1 aggregation, 2 wta, 3 tail, 4 frame.                       */

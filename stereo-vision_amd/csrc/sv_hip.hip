@@ -48,10 +48,11 @@ struct sv_ctx {
     int sw_prof_n = 0;
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
-    int sweep_min_batch = 8;
+    int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: 1.5 frames per workgroup pipeline
     bool attr_sweep[2][4][2] = {}, attr_cost[8] = {};
-    int sweep_cw = 7;                  // compute waves per sweep workgroup (7: two workgroups per CU, 15: one)
+    int sweep_cw = 15;                 // compute waves per sweep workgroup (15: one workgroup per CU, 7: two)
     int n_cu = 256;
+    int last_agg_launches = 0, last_agg_sweeps = 0;  // of the most recent compute call (sv_last_aggregation)
     int fuse_wta_min_batch = 6;  // batches below this run WTA as its own kernel (see run_sgm; crossover measured at 640x480 D=128)
     Buf disp_lr, out;        // i16 [H][W]
     Buf rgb_l, rgb_r;        // u8 [H][W][3] input staging
@@ -489,8 +490,16 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     // Otherwise one launch per path: the first one initialises S and, when `fuse`, the last one
     // carries WTA and never stores S.
     bool wta_done = false;
+    c->last_agg_launches = c->last_agg_sweeps = 0;
     {
-        const bool sweep_ok = !c->debug && D <= 128 && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= c->sweep_min_batch);
+        // The fused sweeps pipeline the bands of a frame through ceil(H / rows-per-band) workgroups and
+        // pay the pipeline fill once per launch: they win once every pipeline streams more than one
+        // frame (measured crossover at 640x480 D=128: ~40 frames on 256 CUs), below that the
+        // per-path kernels are faster.
+        const int sw_rows = 4 * c->sweep_cw, sw_bands = (H + sw_rows - 1) / sw_rows;
+        const int sw_pipes = c->n_cu * (c->sweep_cw == 15 ? 1 : 2) / sw_bands;
+        const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : (3 * (sw_pipes > 0 ? sw_pipes : 1) + 1) / 2;
+        const bool sweep_ok = !c->debug && D <= 128 && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= sw_min);
         const bool sw1 = sweep_ok && (p.path_mask & 0x0Fu) == 0x0Fu;
         const bool sw2 = sw1 && (p.path_mask & 0xF0u) == 0xF0u;
         uint32_t rest = p.path_mask;
@@ -500,12 +509,14 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
             if (rc) return rc;
             rest &= ~0x0Fu;
             first = false;
+            c->last_agg_launches++; c->last_agg_sweeps++;
         }
         if (sw2) {
             int rc = launch_sweep(c, true, nb);
             if (rc) return rc;
             rest = 0;
             wta_done = true;
+            c->last_agg_launches++; c->last_agg_sweeps++;
         }
         if (rest) {
             int last = 7;
@@ -514,6 +525,7 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
                 if (rest & (1u << dir)) {
                     const bool fl = dir == last && fuse;
                     launch_agg(c, dir, (first ? 1 : 0) | (fl ? 2 : 0), nb);
+                    c->last_agg_launches++;
                     first = false;
                     wta_done = wta_done || fl;
                 }
@@ -604,7 +616,7 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     if (const char* e = getenv("SV_FUSE_WTA_MIN_BATCH")) c->fuse_wta_min_batch = atoi(e);  // tuning knobs
     if (const char* e = getenv("SV_SWEEP_MIN_BATCH")) c->sweep_min_batch = atoi(e);
     if (const char* e = getenv("SV_SWEEP_MODE")) c->sweep_mode = atoi(e);
-    if (const char* e = getenv("SV_SWEEP_CW")) c->sweep_cw = atoi(e) == 15 ? 15 : 7;
+    if (const char* e = getenv("SV_SWEEP_CW")) c->sweep_cw = atoi(e) == 7 ? 7 : 15;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("SV_SWEEP_NCU")) c->n_cu = atoi(e) > 0 ? atoi(e) : c->n_cu;  // tests: few groups, many frames each
     HIPCHK(c, hipHostMalloc((void**)&c->sw_error, sizeof(unsigned int), hipHostMallocMapped));
@@ -968,6 +980,13 @@ int sv_filter_wls_host(sv_ctx* c, const int16_t* d16, size_t ds, const uint8_t* 
     HIPCHK(c, copy2d(out16, os16, c->wls_o16.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     if (vis) HIPCHK(c, copy2d(out8, os8, c->wls_o8.p, W, W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_last_aggregation(const sv_ctx* c, int* n_launches, int* n_fused_sweeps) {
+    if (!c || !n_launches || !n_fused_sweeps) return SV_ERR_INVALID_ARG;
+    *n_launches = c->last_agg_launches;
+    *n_fused_sweeps = c->last_agg_sweeps;
     return SV_OK;
 }
 

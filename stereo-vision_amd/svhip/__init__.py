@@ -30,7 +30,7 @@ EXPORTS = (
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
     "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host",
-    "sv_synchronize", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
+    "sv_synchronize", "sv_last_aggregation", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
     "sv_algorithmic_bytes", "sv_last_error", "sv_version")
 
@@ -106,6 +106,7 @@ def load():
     L.sv_get_maps_host.argtypes = [vp, i32, vp, vp]
     L.sv_get_mapper_host.argtypes = [vp, i32, vp]
     L.sv_synchronize.argtypes = [vp]
+    L.sv_last_aggregation.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.sv_set_debug.argtypes = [vp, i32]
     L.sv_debug_read_volume_host.argtypes = [vp, i32, vp, sz]
     L.sv_debug_read_plane_host.argtypes = [vp, i32, vp]
@@ -278,6 +279,12 @@ class Matcher:
             self._h, n, C.c_void_p(disp_t.data_ptr()), C.c_void_p(vis_t.data_ptr()) if vis_t is not None else None,
             C.c_void_p(guide_t.data_ptr()), C.c_void_p(out_t.data_ptr()),
             C.c_void_p(vis_out_t.data_ptr()) if vis_out_t is not None else None))
+
+    def last_aggregation(self):
+        """(aggregation launches, fused-sweep launches among them) of the last compute call."""
+        a, b = C.c_int(), C.c_int()
+        self._chk(self._L.sv_last_aggregation(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def synchronize(self):
         self._chk(self._L.sv_synchronize(self._h))
