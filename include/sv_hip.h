@@ -256,7 +256,11 @@ int sv_depth_dev(sv_ctx* ctx, const int16_t* disp16_dev, const float* mapper_dev
  * per pass over C),
  * 1 = debug (per-path kernels, S always materialised), 2 = WTA fused into the
  * last path whatever the batch size, 3 = fused sweeps whatever the batch size,
- * 4 = never the fused sweeps (2-4 let tests exercise each variant on one frame). */
+ * 4 = plain per-path launches (no fused sweeps, no concurrent paths), 5 = the
+ * concurrent-path variant (every path on its own stream into its own volume,
+ * then one sum + WTA kernel; what mode 0 picks for batches that leave most of
+ * the chip idle, up to 8 frames at 640x480) whatever the batch size.  Modes
+ * 2-5 let tests exercise each variant on one frame.                           */
 int sv_set_debug(sv_ctx* ctx, int mode);
 int sv_debug_read_volume_host(sv_ctx* ctx, int which, int16_t* vol_host, size_t n_elems);
 /* which: 0 = disp before LR check, 1 = raw integer disparity, 2 = minS,

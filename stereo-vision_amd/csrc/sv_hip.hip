@@ -52,6 +52,12 @@ struct sv_ctx {
     bool attr_sweep[2][4][2] = {}, attr_cost[8] = {};
     int sweep_cw = 15;                 // compute waves per sweep workgroup (15: one workgroup per CU, 7: two)
     int n_cu = 256;
+    // concurrent paths for small batches (run_paths_fanout)
+    hipStream_t side[8] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[8] = {};
+    bool side_ok = false;
+    Buf Lbuf[8];
+    int fanout_mode = 0;               // 0 auto, 1 always, -1 never
     int last_agg_launches = 0, last_agg_sweeps = 0;  // of the most recent compute call (sv_last_aggregation)
     int fuse_wta_min_batch = 6;  // batches below this run WTA as its own kernel (see run_sgm; crossover measured at 640x480 D=128)
     Buf disp_lr, out;        // i16 [H][W]
@@ -173,7 +179,7 @@ struct DevGuard {
 };
 
 template <int N>
-void launch_agg_n(sv_ctx* c, int dir, int mode, int nb) {
+void launch_agg_n(sv_ctx* c, int dir, int mode, int nb, uint32_t* Sout, hipStream_t st) {
     static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
@@ -183,12 +189,12 @@ void launch_agg_n(sv_ctx* c, int dir, int mode, int nb) {
     const dim3 grid((nchains + 3) / 4, nb), block(64);
     const uint32_t P1P1 = (uint32_t)c->prm.P1 * 0x10001u, P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
     const uint32_t* Cv = (const uint32_t*)c->C.p;
-    uint32_t* Sv = (uint32_t*)c->S.p;
+    uint32_t* Sv = Sout;
     constexpr int U = N <= 4 ? 4 : 2;
     uint2* rec = (uint2*)c->rec.p;
     const int uq = c->prm.uniqueness_ratio;
 #define SV_LAUNCH_AGG(V, M) \
-    hipLaunchKernelGGL((svk::k_agg<N, V, M, U>), grid, block, 0, c->stream, Cv, Sv, W1, H, dx, dy, P1P1, P2P2, rec, uq)
+    hipLaunchKernelGGL((svk::k_agg<N, V, M, U>), grid, block, 0, st, Cv, Sv, W1, H, dx, dy, P1P1, P2P2, rec, uq)
     if (vert) {
         switch (mode) {
             case 0: SV_LAUNCH_AGG(true, 0); break;
@@ -207,17 +213,69 @@ void launch_agg_n(sv_ctx* c, int dir, int mode, int nb) {
 #undef SV_LAUNCH_AGG
 }
 
-void launch_agg(sv_ctx* c, int dir, int mode, int nb) {
+void launch_agg_to(sv_ctx* c, int dir, int mode, int nb, uint32_t* Sout, hipStream_t st) {
     switch (c->prm.num_disparities / 32) {
-        case 1: launch_agg_n<1>(c, dir, mode, nb); break;
-        case 2: launch_agg_n<2>(c, dir, mode, nb); break;
-        case 3: launch_agg_n<3>(c, dir, mode, nb); break;
-        case 4: launch_agg_n<4>(c, dir, mode, nb); break;
-        case 5: launch_agg_n<5>(c, dir, mode, nb); break;
-        case 6: launch_agg_n<6>(c, dir, mode, nb); break;
-        case 7: launch_agg_n<7>(c, dir, mode, nb); break;
-        default: launch_agg_n<8>(c, dir, mode, nb); break;
+        case 1: launch_agg_n<1>(c, dir, mode, nb, Sout, st); break;
+        case 2: launch_agg_n<2>(c, dir, mode, nb, Sout, st); break;
+        case 3: launch_agg_n<3>(c, dir, mode, nb, Sout, st); break;
+        case 4: launch_agg_n<4>(c, dir, mode, nb, Sout, st); break;
+        case 5: launch_agg_n<5>(c, dir, mode, nb, Sout, st); break;
+        case 6: launch_agg_n<6>(c, dir, mode, nb, Sout, st); break;
+        case 7: launch_agg_n<7>(c, dir, mode, nb, Sout, st); break;
+        default: launch_agg_n<8>(c, dir, mode, nb, Sout, st); break;
     }
+}
+void launch_agg(sv_ctx* c, int dir, int mode, int nb) { launch_agg_to(c, dir, mode, nb, (uint32_t*)c->S.p, c->stream); }
+
+template <int N>
+void launch_sum_wta_n(sv_ctx* c, const svk::PathBufs& pb, int nb) {
+    const size_t npx = (size_t)(c->W - c->prm.num_disparities) * c->H;
+    hipLaunchKernelGGL((svk::k_sum_wta<N>), dim3((unsigned)((npx * 16 + 255) / 256), nb), dim3(256), 0, c->stream, pb,
+                       (uint2*)c->rec.p, c->W, c->H, c->prm.uniqueness_ratio);
+}
+
+// Small batches are latency-bound (one path launch of one 640x480 frame is 128 waves on 1024
+// SIMDs), so the paths run side by side: every path on its own stream, writing its own L volume,
+// then one streaming kernel sums them and runs WTA.  More bytes (3V per path instead of ~2.75V)
+// but the eight recurrences overlap: 0.84 -> 0.3x ms for a single frame.
+int run_paths_fanout(sv_ctx* c, int nb) {
+    const sv_params& p = c->prm;
+    const size_t vol = (size_t)(c->W - p.num_disparities) * c->H * p.num_disparities * 2 * nb;
+    if (!c->side_ok) {
+        for (int i = 0; i < 8; i++) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        }
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        c->side_ok = true;
+    }
+    svk::PathBufs pb;
+    pb.n = 0;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int dir = 0; dir < 8; dir++)
+        if (p.path_mask & (1u << dir)) {
+            const int i = pb.n++;
+            int rc = ensure(c, c->Lbuf[i], vol);
+            if (rc) return rc;
+            HIPCHK(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+            launch_agg_to(c, dir, /*FIRST: store L*/ 1, nb, (uint32_t*)c->Lbuf[i].p, c->side[i]);
+            HIPCHK(c, hipEventRecord(c->ev_join[i], c->side[i]));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
+            pb.L[i] = (const uint32_t*)c->Lbuf[i].p;
+            c->last_agg_launches++;
+        }
+    for (int i = pb.n; i < 8; i++) pb.L[i] = pb.L[0];
+    switch (p.num_disparities / 32) {
+        case 1: launch_sum_wta_n<1>(c, pb, nb); break;
+        case 2: launch_sum_wta_n<2>(c, pb, nb); break;
+        case 3: launch_sum_wta_n<3>(c, pb, nb); break;
+        case 4: launch_sum_wta_n<4>(c, pb, nb); break;
+        case 5: launch_sum_wta_n<5>(c, pb, nb); break;
+        case 6: launch_sum_wta_n<6>(c, pb, nb); break;
+        case 7: launch_sum_wta_n<7>(c, pb, nb); break;
+        default: launch_sum_wta_n<8>(c, pb, nb); break;
+    }
+    return SV_OK;
 }
 
 template <int N>
@@ -518,6 +576,17 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
             wta_done = true;
             c->last_agg_launches++; c->last_agg_sweeps++;
         }
+        // few frames: all remaining paths at once, each into its own volume, then sum + WTA
+        const int n_rest = __builtin_popcount(rest);
+        const long waves_per_launch = (long)nb * ((W - D > H ? W - D : H) + 3) / 4;
+        const bool fan = !c->debug && !c->force_fuse && first && n_rest >= 2 && c->fanout_mode >= 0 &&
+                         (c->fanout_mode > 0 || waves_per_launch <= 4L * c->n_cu);
+        if (fan) {
+            int rc = run_paths_fanout(c, nb);
+            if (rc) return rc;
+            rest = 0;
+            wta_done = true;
+        }
         if (rest) {
             int last = 7;
             while (!(rest & (1u << last))) last--;
@@ -637,6 +706,11 @@ int sv_destroy(sv_ctx* c) {
                           &c->wls_v, &c->wls_o16, &c->wls_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
             for (Buf* b : all) release(*b);
             if (c->sw_error) (void)hipHostFree(c->sw_error);
+            for (int i = 0; i < 8; i++) release(c->Lbuf[i]);
+            if (c->side_ok) {
+                for (int i = 0; i < 8; i++) { (void)hipStreamDestroy(c->side[i]); (void)hipEventDestroy(c->ev_join[i]); }
+                (void)hipEventDestroy(c->ev_fork);
+            }
             if (c->ev_ok)
                 for (int r = 0; r < sv_ctx::EV_RING; r++)
                     for (int i = 0; i < sv_ctx::EV_PER; i++)
@@ -1013,6 +1087,7 @@ int sv_set_debug(sv_ctx* c, int enable) {
     c->debug = enable == 1;
     c->force_fuse = enable == 2;
     c->sweep_mode = enable == 3 ? 1 : (enable == 4 ? -1 : 0);
+    c->fanout_mode = enable == 5 ? 1 : (enable == 4 || enable == 2 ? -1 : 0);
     return SV_OK;
 }
 

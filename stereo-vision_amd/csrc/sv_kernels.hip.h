@@ -608,6 +608,34 @@ __global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, uin
     rec[(size_t)blockIdx.y * npx + p] = r;
 }
 
+// Small batches: the paths run concurrently, each writing its own L volume (k_agg in FIRST mode on
+// its own stream); this kernel adds them up with the saturation of safe_add (aggregation.cu:4-10:
+// min(S + L, 32767) path by path = min(sum, 32767), all terms >= 0) and runs WTA on the sum.
+struct PathBufs {
+    const uint32_t* L[8];
+    int n;
+};
+template <int N>
+__global__ __launch_bounds__(256) void k_sum_wta(PathBufs pb, uint2* __restrict__ rec, int W, int H, int uniq) {
+    const int D = 32 * N, W1 = W - D;
+    const int q = threadIdx.x & 15;
+    const size_t pid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const size_t npx = (size_t)W1 * H;
+    const size_t p = min(pid, npx - 1);  // surplus groups repeat the last pixel (same value, same wave)
+    const int y = (int)(p / W1), xl = (int)(p - (size_t)y * W1);
+    const size_t off = ((size_t)blockIdx.y * npx + p) * 16 * N + q * N;
+    uint32_t acc[N], v[N];
+    load_regs<N>(pb.L[0] + off, acc);
+    for (int i = 1; i < pb.n; i++) {
+        load_regs<N>(pb.L[i] + off, v);
+#pragma unroll
+        for (int k = 0; k < N; k++) acc[k] = pk_add_sat(acc[k], v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) acc[k] = pk_min(acc[k], 0x7FFF7FFFu);
+    rec[((size_t)blockIdx.y * H + y) * W + xl + D] = wta_record<N>(acc, q, make_uniq(uniq));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage 5: left-right check, one workgroup per image row.  Result of lrcheck
 // (aggregation.cu:691-735): disp2/disp2cost are built right-to-left with a strict '>' (ties keep

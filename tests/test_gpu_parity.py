@@ -36,7 +36,12 @@ def test_stages_bit_exact(gpu, W, H, D, paths, flags, bs, seed):
     ref, st = svref.sgbm(left, right, po, stages=("C", "S", "disp_wta", "raw", "mins", "disp_lr"))
     m = svhip.Matcher(W, H, ph)
     assert np.array_equal(m.compute_gray(left, right), ref), "final disparity16 differs (production path, one frame)"
-    m.set_debug(2)                       # large-batch production path: WTA fused into the last path, S never stored
+    m.set_debug(4)                       # plain per-path launches + WTA kernel
+    assert np.array_equal(m.compute_gray(left, right), ref), "final disparity16 differs (per-path launches)"
+    m.set_debug(5)                       # concurrent paths into separate volumes + sum/WTA kernel
+    assert np.array_equal(m.compute_gray(left, right), ref), "final disparity16 differs (concurrent paths)"
+    assert np.array_equal(m.debug_plane(2), st["mins"]), "minS differs (concurrent paths)"
+    m.set_debug(2)                       # mid-size batches: WTA fused into the last path, S never stored
     fused = m.compute_gray(left, right)
     assert np.array_equal(fused, ref), "final disparity16 differs (fused WTA)"
     assert np.array_equal(m.debug_plane(2), st["mins"]), "minS differs (fused WTA)"
@@ -63,6 +68,8 @@ def test_single_paths(gpu, mask):
     m = svhip.Matcher(W, H, ph)
     assert np.array_equal(m.compute_gray(left, right), ref)
     m.set_debug(2)
+    assert np.array_equal(m.compute_gray(left, right), ref)
+    m.set_debug(5)
     assert np.array_equal(m.compute_gray(left, right), ref)
     m.set_debug(True)
     got = m.compute_gray(left, right)
