@@ -38,7 +38,7 @@ struct sv_ctx {
 
     // device buffers
     Buf img_l, img_r;        // u8 [H][W] staging for the host entry points
-    Buf stat_l, stat_r;      // uint2 [H][W]
+    Buf stat_l, stat_r;      // left: uint2 [H][W] records; right: u16 planes [6][2][H][pitch]
     Buf C, S;                // u16 [H][W1][D]
     Buf rec;                 // WTA records {disp16, raw, minS, 0} [H][W] x 8 bytes
     bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
@@ -49,13 +49,10 @@ struct sv_ctx {
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: 1.5 frames per workgroup pipeline
-    bool attr_sweep[2][4][2] = {}, attr_cost[8] = {};
+    bool attr_sweep[2][4][2] = {}, attr_cost2[8] = {};
     int sweep_cw = 15;                 // compute waves per sweep workgroup (15: one workgroup per CU, 7: two)
     int n_cu = 256;
     // concurrent paths for small batches (run_paths_fanout)
-    hipStream_t side[8] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[8] = {};
-    bool side_ok = false;
     Buf Lbuf[8];
     int fanout_mode = 0;               // 0 auto, 1 always, -1 never
     int last_agg_launches = 0, last_agg_sweeps = 0;  // of the most recent compute call (sv_last_aggregation)
@@ -149,7 +146,8 @@ int alloc_core(sv_ctx* c) {
     const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities * c->batch;
     int rc;
     if ((rc = ensure(c, c->stat_l, npx * 8))) return rc;
-    if ((rc = ensure(c, c->stat_r, npx * 8))) return rc;
+    // right statistics: six u16 planes x two copies (k_stats_planes)
+    if ((rc = ensure(c, c->stat_r, (size_t)12 * c->H * svk::cost_plane_pitch(c->W) * 2 * c->batch))) return rc;
     if ((rc = ensure(c, c->C, nvol * 2))) return rc;
     if ((rc = ensure(c, c->S, nvol * 2))) return rc;
     if ((rc = ensure(c, c->rec, npx * 8))) return rc;
@@ -228,92 +226,91 @@ void launch_agg_to(sv_ctx* c, int dir, int mode, int nb, uint32_t* Sout, hipStre
 void launch_agg(sv_ctx* c, int dir, int mode, int nb) { launch_agg_to(c, dir, mode, nb, (uint32_t*)c->S.p, c->stream); }
 
 template <int N>
-void launch_sum_wta_n(sv_ctx* c, const svk::PathBufs& pb, int nb) {
-    const size_t npx = (size_t)(c->W - c->prm.num_disparities) * c->H;
+void launch_paths_sum_n(sv_ctx* c, const svk::PathSet& ps, const svk::PathBufs& pb, int nb) {
+    const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
+    constexpr int U = N <= 4 ? 4 : 2;
+    const int nch = W1 > H ? W1 : H;
+    hipLaunchKernelGGL((svk::k_agg_paths<N, U>), dim3((nch + 3) / 4, nb, pb.n), dim3(64), 0, c->stream, (const uint32_t*)c->C.p, ps,
+                       W1, H, (uint32_t)c->prm.P1 * 0x10001u, (uint32_t)c->prm.P2 * 0x10001u);
+    const size_t npx = (size_t)W1 * H;
     hipLaunchKernelGGL((svk::k_sum_wta<N>), dim3((unsigned)((npx * 16 + 255) / 256), nb), dim3(256), 0, c->stream, pb,
                        (uint2*)c->rec.p, c->W, c->H, c->prm.uniqueness_ratio);
 }
 
 // Small batches are latency-bound (one path launch of one 640x480 frame is 128 waves on 1024
-// SIMDs), so the paths run side by side: every path on its own stream, writing its own L volume,
-// then one streaming kernel sums them and runs WTA.  More bytes (3V per path instead of ~2.75V)
-// but the eight recurrences overlap: 0.84 -> 0.3x ms for a single frame.
+// SIMDs), so all paths run side by side in one launch, each writing its own L volume, then one
+// streaming kernel sums them and runs WTA.  More bytes (3V per path instead of ~2.75V) but the
+// eight recurrences overlap.
 int run_paths_fanout(sv_ctx* c, int nb) {
+    static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const sv_params& p = c->prm;
     const size_t vol = (size_t)(c->W - p.num_disparities) * c->H * p.num_disparities * 2 * nb;
-    if (!c->side_ok) {
-        for (int i = 0; i < 8; i++) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-        }
-        HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        c->side_ok = true;
-    }
+    svk::PathSet ps;
     svk::PathBufs pb;
     pb.n = 0;
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     for (int dir = 0; dir < 8; dir++)
         if (p.path_mask & (1u << dir)) {
             const int i = pb.n++;
             int rc = ensure(c, c->Lbuf[i], vol);
             if (rc) return rc;
-            HIPCHK(c, hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
-            launch_agg_to(c, dir, /*FIRST: store L*/ 1, nb, (uint32_t*)c->Lbuf[i].p, c->side[i]);
-            HIPCHK(c, hipEventRecord(c->ev_join[i], c->side[i]));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
+            ps.L[i] = (uint32_t*)c->Lbuf[i].p;
+            ps.dx[i] = (signed char)DX[dir];
+            ps.dy[i] = (signed char)DY[dir];
             pb.L[i] = (const uint32_t*)c->Lbuf[i].p;
-            c->last_agg_launches++;
         }
-    for (int i = pb.n; i < 8; i++) pb.L[i] = pb.L[0];
+    for (int i = pb.n; i < 8; i++) { ps.L[i] = ps.L[0]; ps.dx[i] = ps.dx[0]; ps.dy[i] = ps.dy[0]; pb.L[i] = pb.L[0]; }
+    c->last_agg_launches += 1;
     switch (p.num_disparities / 32) {
-        case 1: launch_sum_wta_n<1>(c, pb, nb); break;
-        case 2: launch_sum_wta_n<2>(c, pb, nb); break;
-        case 3: launch_sum_wta_n<3>(c, pb, nb); break;
-        case 4: launch_sum_wta_n<4>(c, pb, nb); break;
-        case 5: launch_sum_wta_n<5>(c, pb, nb); break;
-        case 6: launch_sum_wta_n<6>(c, pb, nb); break;
-        case 7: launch_sum_wta_n<7>(c, pb, nb); break;
-        default: launch_sum_wta_n<8>(c, pb, nb); break;
+        case 1: launch_paths_sum_n<1>(c, ps, pb, nb); break;
+        case 2: launch_paths_sum_n<2>(c, ps, pb, nb); break;
+        case 3: launch_paths_sum_n<3>(c, ps, pb, nb); break;
+        case 4: launch_paths_sum_n<4>(c, ps, pb, nb); break;
+        case 5: launch_paths_sum_n<5>(c, ps, pb, nb); break;
+        case 6: launch_paths_sum_n<6>(c, ps, pb, nb); break;
+        case 7: launch_paths_sum_n<7>(c, ps, pb, nb); break;
+        default: launch_paths_sum_n<8>(c, ps, pb, nb); break;
     }
     return SV_OK;
 }
 
 template <int N>
-int launch_cost_n(sv_ctx* c, int nb) {
+int launch_cost2_n(sv_ctx* c, int nb) {
+    constexpr int NT = 512, NCOL = NT / 16;
     const sv_params& p = c->prm;
     const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
-    const svk::CostLds lay = svk::cost_lds_layout(D, r);
-    bool* attr_set = c->attr_cost;  // per context: the attribute is per device
-    if (lay.total > 48 * 1024 && !attr_set[N - 1]) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_cost<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const int TX = NCOL - 2 * r, WP = svk::cost_plane_pitch(W);
+    const size_t lds = (size_t)(2 * NCOL + (2 * r + 2) * TX) * (16 * N) * 4;
+    bool* attr_set = c->attr_cost2;  // per context: the attribute is per device
+    if (lds > 48 * 1024 && !attr_set[N - 1]) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_cost2<N, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024));
         attr_set[N - 1] = true;
     }
-    // bands of rows: enough workgroups to fill 256 CUs, few enough that the 2r+1-row prologue stays small
+    const int ntx = (W1 + TX - 1) / TX;
+    // bands of rows: enough workgroups to fill 256 CUs twice, few enough that the 2r+1-row prologue stays small
     int yband = 60;
-    while (yband > 24 && (size_t)((W1 + svk::COST_TX - 1) / svk::COST_TX) * ((H + yband - 1) / yband) * nb < 1024) yband -= 12;
-    const dim3 grid((W1 + svk::COST_TX - 1) / svk::COST_TX, (H + yband - 1) / yband, nb);
-    hipLaunchKernelGGL((svk::k_cost<N>), grid, dim3(256), (size_t)lay.total, c->stream, (const uint2*)c->stat_l.p,
-                       (const uint2*)c->stat_r.p, (uint32_t*)c->C.p, W, H, r, yband, (uint32_t)p.P2 * 0x10001u,
-                       (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0);
+    while (yband > 24 && (size_t)ntx * ((H + yband - 1) / yband) * nb < 512) yband -= 12;
+    hipLaunchKernelGGL((svk::k_cost2<N, NT>), dim3(ntx, (H + yband - 1) / yband, nb), dim3(NT), lds, c->stream,
+                       (const uint2*)c->stat_l.p, (const uint16_t*)c->stat_r.p, (uint32_t*)c->C.p, W, H, WP, r, yband,
+                       (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0);
     if (H > 1)
         hipLaunchKernelGGL(svk::k_cost_col0, dim3(H - 1, nb), dim3(128), 0, c->stream, (uint32_t*)c->C.p, W1, H, D / 2,
                            (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0);
     return SV_OK;
 }
-int launch_cost(sv_ctx* c, int nb) {
+int launch_cost2(sv_ctx* c, int nb) {
     switch (c->prm.num_disparities / 32) {
-        case 1: return launch_cost_n<1>(c, nb);
-        case 2: return launch_cost_n<2>(c, nb);
-        case 3: return launch_cost_n<3>(c, nb);
-        case 4: return launch_cost_n<4>(c, nb);
-        case 5: return launch_cost_n<5>(c, nb);
-        case 6: return launch_cost_n<6>(c, nb);
-        case 7: return launch_cost_n<7>(c, nb);
-        default: return launch_cost_n<8>(c, nb);
+        case 1: return launch_cost2_n<1>(c, nb);
+        case 2: return launch_cost2_n<2>(c, nb);
+        case 3: return launch_cost2_n<3>(c, nb);
+        case 4: return launch_cost2_n<4>(c, nb);
+        case 5: return launch_cost2_n<5>(c, nb);
+        case 6: return launch_cost2_n<6>(c, nb);
+        case 7: return launch_cost2_n<7>(c, nb);
+        default: return launch_cost2_n<8>(c, nb);
     }
 }
-
 template <int N>
 void launch_wta_n(sv_ctx* c, int nb) {
     const size_t npx = (size_t)c->W * c->H;
@@ -535,12 +532,12 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     const bool fuse = !c->debug && (c->force_fuse || (long)nb * (W - D) >= (long)c->fuse_wta_min_batch * 512);
     mark();
     // 1. prefilter + BT statistics
-    hipLaunchKernelGGL(svk::k_stats, dim3((W + 255) / 256, H, 2 * nb), dim3(256), 0, c->stream, left, right, (uint2*)c->stat_l.p,
-                       (uint2*)c->stat_r.p, W, H, p.pre_filter_cap);
+    hipLaunchKernelGGL(svk::k_stats_planes, dim3((W + 255) / 256, H, 2 * nb), dim3(256), 0, c->stream, left, right,
+                       (uint2*)c->stat_l.p, (uint16_t*)c->stat_r.p, W, H, svk::cost_plane_pitch(W), p.pre_filter_cap);
     mark();
     // 2. matching cost volume C
     {
-        int rc = launch_cost(c, nb);
+        int rc = launch_cost2(c, nb);
         if (rc) return rc;
     }
     mark();
@@ -707,10 +704,7 @@ int sv_destroy(sv_ctx* c) {
             for (Buf* b : all) release(*b);
             if (c->sw_error) (void)hipHostFree(c->sw_error);
             for (int i = 0; i < 8; i++) release(c->Lbuf[i]);
-            if (c->side_ok) {
-                for (int i = 0; i < 8; i++) { (void)hipStreamDestroy(c->side[i]); (void)hipEventDestroy(c->ev_join[i]); }
-                (void)hipEventDestroy(c->ev_fork);
-            }
+
             if (c->ev_ok)
                 for (int r = 0; r < sv_ctx::EV_RING; r++)
                     for (int i = 0; i < sv_ctx::EV_PER; i++)

@@ -53,6 +53,9 @@ __device__ __forceinline__ uint32_t row16_or_u32(uint32_t v) {
     v |= dpp<DPP_ROW_MIRROR>(0u, v);
     return v;
 }
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {  // each half = max(a - b, 0)
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
 // saturating packed add (v_pk_add_u16 clamp): each half = min(a + b, 65535)
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
@@ -122,15 +125,35 @@ __device__ __forceinline__ int raw_at(const uint8_t* __restrict__ img, int W, in
     return img[(size_t)y * W + x];
 }
 
-__global__ __launch_bounds__(256) void k_stats(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
-                                                uint2* __restrict__ stat_l, uint2* __restrict__ stat_r, int W, int H,
-                                                int cap) {
+// ---------------------------------------------------------------------------------------------
+// Stage 1+2: prefilter + BT statistics, then the matching cost volume C in one fused kernel.
+// Result of get_gradient (costs.cu:116-166) and of get_pixel_diff x2 + get_hsum + get_cost
+// (costs.cu:170-284) without materialising pixDiff or hsum and without the two memsets:
+//   C[y][xl][d] = P2 + sum_{i=-r..r} sum_{k=-r..r} pix[max(y+i,0)][clamp(xl+k,0,W1-1)][d]
+// which is what the reference's running sums equal when no int16 store wraps (sv_check_params),
+// with its two quirks kept: the bottom SH2 rows repeat the last computed row (:279-282, or P2 with
+// SV_FLAG_C_TAIL_P2) and column x = D is overwritten afterwards by k_cost_col0 (:254-267).
+// k_stats_planes writes the LEFT statistics as 8-byte records {g, g0, g1, r, r0, r1} (g = clipped
+// Sobel-x value, r = raw channel with its edge columns forced to ftzero, a0/a1 = min/max of
+// {a, (a+left)/2, (a+right)/2}: what get_pixel_diff recomputes per disparity) and the RIGHT
+// statistics as six planes of u16, reversed in x (index i = W-1-x), each in two copies (the second
+// shifted by one element): a lane that needs the right statistics of x-d for 2N consecutive
+// disparities reads them as N aligned dwords per plane straight from L1/L2 - (stat(x-d),
+// stat(x-d-1)) is already the packed pair the 16-bit VALU wants.  No per-row staging of the right
+// image in LDS, no unpacking, one barrier per image row instead of three.
+// Plane layout: rp[frame][stat 0..5][copy 0..1][H][WP] u16, WP even, >= W + 2.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int cost_plane_pitch(int W) { return (W + 2 + 7) & ~7; }
+
+__global__ __launch_bounds__(256) void k_stats_planes(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                       uint2* __restrict__ stat_l, uint16_t* __restrict__ rp, int W, int H, int WP,
+                                                       int cap) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
-    const size_t fo = (size_t)(blockIdx.z >> 1) * W * H;  // frame offset (batched launch)
-    const uint8_t* img = ((blockIdx.z & 1) ? right : left) + fo;
-    uint2* out = ((blockIdx.z & 1) ? stat_r : stat_l) + fo;
+    const int frame = blockIdx.z >> 1;
+    const bool is_right = blockIdx.z & 1;
+    const uint8_t* img = (is_right ? right : left) + (size_t)frame * W * H;
     int g = grad_at(img, W, H, x, y, cap), r = raw_at(img, W, x, y, cap);
     int gl = x > 0 ? (g + grad_at(img, W, H, x - 1, y, cap)) / 2 : g;
     int gr = x < W - 1 ? (g + grad_at(img, W, H, x + 1, y, cap)) / 2 : g;
@@ -138,177 +161,113 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t* __restrict__ left,
     int rr = x < W - 1 ? (r + raw_at(img, W, x + 1, y, cap)) / 2 : r;
     int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
     int r0 = min(min(rl, rr), r), r1 = max(max(rl, rr), r);
-    out[(size_t)y * W + x] = make_uint2((uint32_t)g | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r << 24),
-                                        (uint32_t)r0 | ((uint32_t)r1 << 8));
-}
-
-// ---------------------------------------------------------------------------------------------
-// Stage 2: matching cost volume C, one fused kernel.  Result of get_pixel_diff x2 + get_hsum +
-// get_cost (costs.cu:170-284) without materialising pixDiff or hsum and without the two memsets:
-//   C[y][xl][d] = P2 + sum_{i=-r..r} sum_{k=-r..r} pix[max(y+i,0)][clamp(xl+k,0,W1-1)][d]
-// which is what the reference's running sums equal when no int16 store wraps (sv_check_params),
-// with its two quirks kept: the bottom SH2 rows repeat the last computed row (:279-282, or P2 with
-// SV_FLAG_C_TAIL_P2) and column x = D is overwritten afterwards by k_cost_col0 (:254-267).
-// A workgroup owns 16 columns x all D and marches down a band of rows.  Per image row it builds
-// the BT costs of its 16 + 2r columns in LDS as packed u16 pairs (packed 16-bit VALU: two
-// disparities per lane-op), takes the 2r+1-tap horizontal sum from LDS, keeps the last 2r+2
-// horizontal sums in an LDS ring and updates the vertical running sum in registers.  Thread
-// (xi = tid/16, q = tid%16) owns the same (column, N disparity pairs) as a k_agg lane, so C is
-// written with the 16-byte stores k_agg reads it back with.
-// ---------------------------------------------------------------------------------------------
-constexpr int COST_TX = 16;
-typedef short ss2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, (ss2)(__builtin_bit_cast(ss2, a) - __builtin_bit_cast(ss2, b)));
-}
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b)));
-}
-__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b)));
-}
-// BT cost of one channel for two disparities at once (costs.cu:180-196): u* are the left pixel's
-// statistics duplicated in both halves, v* the right statistics of (x-d, x-d-1).
-__device__ __forceinline__ uint32_t bt_pk(uint32_t u, uint32_t u0, uint32_t u1, uint32_t v, uint32_t v0, uint32_t v1) {
-    const uint32_t c0 = pk_max_i16(pk_max_i16(pk_sub_i16(u, v1), pk_sub_i16(v0, u)), 0u);
-    const uint32_t c1 = pk_max_i16(pk_max_i16(pk_sub_i16(v, u1), pk_sub_i16(u0, v)), 0u);
-    return pk_min_i16(c0, c1);
-}
-
-struct CostLds {  // byte offsets into dynamic LDS
-    int lp, rv, pix, ring, total, nrv;
-};
-__host__ __device__ inline CostLds cost_lds_layout(int D, int radius) {
-    const int ncol = COST_TX + 2 * radius, D2 = D / 2, ringn = 2 * radius + 2;
-    CostLds L;
-    L.nrv = (ncol + D + 7) & ~3;
-    L.lp = 0;                                    // [ncol] x 32 B: six duplicated left statistics + pad
-    L.rv = L.lp + ncol * 32;                     // [4 copies][6 stats][nrv] u16, reversed in x
-    L.pix = (L.rv + 4 * 6 * L.nrv * 2 + 15) & ~15;  // [ncol][D2] u32
-    L.ring = L.pix + ncol * D2 * 4;              // [ringn][COST_TX][D2] u32
-    L.total = L.ring + ringn * COST_TX * D2 * 4;
-    return L;
-}
-
-template <int N>
-__global__ __launch_bounds__(256) void k_cost(const uint2* __restrict__ stat_l, const uint2* __restrict__ stat_r,
-                                               uint32_t* __restrict__ C, int W, int H, int radius, int yband, uint32_t P2P2,
-                                               int tail_p2) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    constexpr int D = 32 * N, D2 = 16 * N, D4 = 8 * N;
-    const int W1 = W - D, tid = threadIdx.x;
-    const int ncol = COST_TX + 2 * radius, nwin = 2 * radius + 1, ringn = 2 * radius + 2;
-    const CostLds lay = cost_lds_layout(D, radius);
-    const int nrv = lay.nrv;
-    unsigned char* Lp = smem_raw + lay.lp;
-    uint16_t* RV = reinterpret_cast<uint16_t*>(smem_raw + lay.rv);
-    uint32_t* pix = reinterpret_cast<uint32_t*>(smem_raw + lay.pix);
-    uint32_t* ring = reinterpret_cast<uint32_t*>(smem_raw + lay.ring);
-
-    const int xl0 = blockIdx.x * COST_TX;
-    const int y0 = blockIdx.y * yband, y1 = min(y0 + yband, H);
-    const size_t fpx = (size_t)blockIdx.z * W * H;
-    stat_l += fpx;
-    stat_r += fpx;
-    C += (size_t)blockIdx.z * H * W1 * D2;
-    const int xhi = min(xl0 + COST_TX - 1 + radius, W1 - 1) + D;  // largest left x of the tile (+halo)
-    const int xi = tid >> 4, q = tid & 15;
-    const int xl = xl0 + xi;
-    const bool colok = xl < W1;
-    uint32_t* myring = ring + xi * D2 + q * N;
-
-    // BT work items of a row: (tile column j, 4 consecutive disparities d0 = 4t..4t+3); the LDS
-    // addresses of an item do not depend on the row, so they are computed once.
-    // Right statistics sit in LDS reversed in x (index k <-> x = xhi - k, so d ascending = k
-    // ascending) in 4 copies shifted by 0..3 elements: whatever the column's offset, the four
-    // values k0..k0+3 are one aligned ds_read_b64 from copy (k0 & 3).
-    constexpr int MAXU = ((COST_TX + 10) * D4 + 255) / 256;
-    const int nitems = ncol * D4;
-    uint32_t a_lp[MAXU], a_rv[MAXU], a_px[MAXU];
+    if (!is_right) {
+        stat_l[(size_t)frame * W * H + (size_t)y * W + x] =
+            make_uint2((uint32_t)g | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r << 24), (uint32_t)r0 | ((uint32_t)r1 << 8));
+    } else {
+        const int st[6] = {g, g0, g1, r, r0, r1};
+        const int i = W - 1 - x;
+        uint16_t* base = rp + (size_t)frame * 12 * H * WP + (size_t)y * WP;
 #pragma unroll
-    for (int i = 0; i < MAXU; i++) {
-        const int u = min(tid + 256 * i, nitems - 1);
-        const int j = u / D4, t = u - j * D4;
-        const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + D;
-        const int k0 = (xhi - xj) + 4 * t, c = k0 & 3;
-        a_lp[i] = (uint32_t)(j * 32);
-        a_rv[i] = (uint32_t)(((c * 6) * nrv + (k0 - c)) * 2);
-        a_px[i] = (uint32_t)((j * D2 + 2 * t) * 4);
+        for (int s6 = 0; s6 < 6; s6++) {
+            base[(size_t)(2 * s6) * H * WP + i] = (uint16_t)st[s6];
+            if (i >= 1) base[(size_t)(2 * s6 + 1) * H * WP + i - 1] = (uint16_t)st[s6];
+        }
     }
+}
 
-    // The statistics of the NEXT image row are fetched into registers while the current row is
-    // being processed, so the global-load latency is off the per-row critical path.
-    constexpr int RPT = (COST_TX + 2 * 5 + D + 7 + 255) / 256;  // right records per thread (1 or 2)
-    uint2 pre_l = make_uint2(0u, 0u), pre_r[RPT];
+// BT cost of one channel for two disparities: distance of u to [v0,v1] and of v to [u0,u1], the
+// smaller of the two (costs.cu:180-196).  v0 <= v1, so at most one of the two clamped differences
+// is non-zero and an OR joins them.
+__device__ __forceinline__ uint32_t bt_pk2(uint32_t u, uint32_t u0, uint32_t u1, uint32_t v, uint32_t v0, uint32_t v1) {
+    const uint32_t c0 = pk_sub_sat(u, v1) | pk_sub_sat(v0, u);
+    const uint32_t c1 = pk_sub_sat(v, u1) | pk_sub_sat(u0, v);
+    return pk_min(c0, c1);
+}
+
+// Workgroup barrier that orders LDS traffic only (global loads stay in flight across it).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int N, int TAPS>
+__device__ __forceinline__ void window_sum(const uint32_t* __restrict__ p, uint32_t (&hs)[N]) {
+    uint32_t v[TAPS][N];
+#pragma unroll
+    for (int t = 0; t < TAPS; t++) load_regs<N>(p + t * 16 * N, v[t]);
+#pragma unroll
+    for (int t = 0; t < TAPS; t++)
+#pragma unroll
+        for (int k = 0; k < N; k++) hs[k] += v[t][k];  // <= 189 * 11 per half: no carry
+}
+
+// A workgroup of NT threads owns NT/16 tile columns (TX = NT/16 - 2r output columns + the halo of
+// the horizontal window) x all D and marches down a band of rows.  Thread (j = tid/16, q = tid%16):
+// BT phase: the costs of tile column j for its 2N disparities -> LDS; window phase (j < TX): the
+// 2r+1-tap horizontal sum for output column j from LDS, the last 2r+2 sums in a private LDS ring,
+// the vertical running sum in registers, C out with the 16-byte stores k_agg / k_sweep read back.
+template <int N, int NT>
+__global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
+                                               uint32_t* __restrict__ C, int W, int H, int WP, int radius, int yband,
+                                               uint32_t P2P2, int tail_p2) {
+    extern __shared__ __align__(16) uint32_t c2_lds[];
+    constexpr int D = 32 * N, D2 = 16 * N, NCOL = NT / 16;
+    const int W1 = W - D, tid = threadIdx.x, j = tid >> 4, q = tid & 15;
+    const int TX = NCOL - 2 * radius, ringn = 2 * radius + 2;
+    uint32_t* const pix = c2_lds;                      // [2][NCOL][D2]
+    uint32_t* const ring = pix + 2 * NCOL * D2;        // [ringn][TX][D2]
+    const int xl0 = blockIdx.x * TX;
+    const int y0 = blockIdx.y * yband, y1 = min(y0 + yband, H);
+    stat_l += (size_t)blockIdx.z * W * H;
+    const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)blockIdx.z * 12 * H * WP);
+    C += (size_t)blockIdx.z * H * W1 * D2;
+    // BT item of this thread: tile column j (clamped into the computable band), disparities 2N*q ..
+    const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + D;
+    const int e = (W - 1 - xj) + 2 * N * q;            // reversed index of x - d for the first disparity
+    const int cpy = e & 1;
+    const size_t plane = (size_t)H * WP / 2;           // dwords per plane copy
+    const uint32_t* rbase = rp32 + (size_t)cpy * plane + (size_t)((e - cpy) >> 1);
+    const int xl = xl0 + j;
+    const bool colok = j < TX && xl < W1;
+    uint32_t* const mypix = pix + j * D2 + q * N;
+    uint32_t* const myring = ring + j * D2 + q * N;
+
+    uint2 lrec;
+    uint32_t rs[6][N];
     auto prefetch = [&](int ry) {
         ry = min(ry, H - 1);
-        const uint2* lrow = stat_l + (size_t)ry * W;
-        const uint2* rrow = stat_r + (size_t)ry * W;
-        if (tid < ncol) pre_l = lrow[min(max(xl0 - radius + tid, 0), W1 - 1) + D];
+        lrec = stat_l[(size_t)ry * W + xj];
 #pragma unroll
-        for (int i = 0; i < RPT; i++) pre_r[i] = rrow[max(xhi - (tid + 256 * i), 0)];
+        for (int s6 = 0; s6 < 6; s6++) load_regs<N>(rbase + (size_t)(2 * s6) * plane + (size_t)ry * (WP / 2), rs[s6]);
     };
-
-    // horizontal box sums of image row ry (whose statistics are in pre_l / pre_r) for this thread's
-    // (column, N pairs) -> hs[N], ring[ry]
+    // horizontal box sums of image row ry (operands in lrec / rs) -> hs[N], ring[ry]
     auto hs_row = [&](int ry, uint32_t (&hs)[N]) {
-        __syncthreads();  // previous row's pix / statistics fully consumed
-        if (tid < ncol) {
-            const uint2 r = pre_l;
-            uint4 a;
-            a.x = (r.x & 0xFFu) * 0x10001u;          // g
-            a.y = ((r.x >> 8) & 0xFFu) * 0x10001u;   // g0
-            a.z = ((r.x >> 16) & 0xFFu) * 0x10001u;  // g1
-            a.w = (r.x >> 24) * 0x10001u;            // r
-            *reinterpret_cast<uint4*>(Lp + tid * 32) = a;
-            *reinterpret_cast<uint2*>(Lp + tid * 32 + 16) = make_uint2((r.y & 0xFFu) * 0x10001u, ((r.y >> 8) & 0xFFu) * 0x10001u);
-        }
+        const uint32_t ug = (lrec.x & 0xFFu) * 0x10001u, ug0 = ((lrec.x >> 8) & 0xFFu) * 0x10001u;
+        const uint32_t ug1 = ((lrec.x >> 16) & 0xFFu) * 0x10001u, ur = (lrec.x >> 24) * 0x10001u;
+        const uint32_t ur0 = (lrec.y & 0xFFu) * 0x10001u, ur1 = ((lrec.y >> 8) & 0xFFu) * 0x10001u;
+        uint32_t pv[N];
 #pragma unroll
-        for (int i = 0; i < RPT; i++) {
-            const int k = tid + 256 * i;
-            if (k < nrv) {
-                const uint2 r = pre_r[i];
-                const uint16_t st[6] = {(uint16_t)(r.x & 0xFFu), (uint16_t)((r.x >> 8) & 0xFFu), (uint16_t)((r.x >> 16) & 0xFFu),
-                                        (uint16_t)(r.x >> 24), (uint16_t)(r.y & 0xFFu), (uint16_t)((r.y >> 8) & 0xFFu)};
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    if (k >= c) {
-#pragma unroll
-                        for (int s = 0; s < 6; s++) RV[(c * 6 + s) * nrv + k - c] = st[s];
-                    }
-            }
-        }
+        for (int k = 0; k < N; k++)  // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
+            pv[k] = bt_pk2(ug, ug0, ug1, rs[0][k], rs[1][k], rs[2][k]) + ((bt_pk2(ur, ur0, ur1, rs[3][k], rs[4][k], rs[5][k]) >> 2) & 0x3FFF3FFFu);
+        uint32_t* pw = mypix + (ry & 1) * (NCOL * D2);
+        store_regs<N>(pw, pv);
         prefetch(ry + 1);
-        __syncthreads();
-        const unsigned char* RVb = reinterpret_cast<const unsigned char*>(RV);
-#pragma unroll
-        for (int i = 0; i < MAXU; i++) {
-            if (tid + 256 * i < nitems) {
-                const uint4 la = *reinterpret_cast<const uint4*>(Lp + a_lp[i]);
-                const uint2 lb = *reinterpret_cast<const uint2*>(Lp + a_lp[i] + 16);
-                const unsigned char* rv = RVb + a_rv[i];
-                const uint2 v = *reinterpret_cast<const uint2*>(rv);
-                const uint2 v0 = *reinterpret_cast<const uint2*>(rv + nrv * 2);
-                const uint2 v1 = *reinterpret_cast<const uint2*>(rv + nrv * 4);
-                const uint2 w = *reinterpret_cast<const uint2*>(rv + nrv * 6);
-                const uint2 w0 = *reinterpret_cast<const uint2*>(rv + nrv * 8);
-                const uint2 w1 = *reinterpret_cast<const uint2*>(rv + nrv * 10);
-                // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
-                const uint32_t p0 = bt_pk(la.x, la.y, la.z, v.x, v0.x, v1.x) + ((bt_pk(la.w, lb.x, lb.y, w.x, w0.x, w1.x) >> 2) & 0x3FFF3FFFu);
-                const uint32_t p1 = bt_pk(la.x, la.y, la.z, v.y, v0.y, v1.y) + ((bt_pk(la.w, lb.x, lb.y, w.y, w0.y, w1.y) >> 2) & 0x3FFF3FFFu);
-                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(pix) + a_px[i]) = make_uint2(p0, p1);
-            }
-        }
-        __syncthreads();
+        // pix[ry & 1] complete; its previous contents (row ry-2) were consumed before the last barrier.
+        // LDS only: __syncthreads() would also wait for the prefetch just issued (vmcnt(0)).
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < N; k++) hs[k] = 0;
-        for (int t = 0; t < nwin; t++) {
-            uint32_t v[N];
-            load_regs<N>(pix + (xi + t) * D2 + q * N, v);
-#pragma unroll
-            for (int k = 0; k < N; k++) hs[k] += v[k];  // <= 189 * 11 per half: no carry
+        if (j < TX) {
+            // all taps of the window in flight at once (a loop with a run-time trip count waits for
+            // every LDS read before the next: 7 x the LDS latency per row)
+            switch (radius) {
+                case 0: window_sum<N, 1>(pw, hs); break;
+                case 1: window_sum<N, 3>(pw, hs); break;
+                case 2: window_sum<N, 5>(pw, hs); break;
+                case 3: window_sum<N, 7>(pw, hs); break;
+                case 4: window_sum<N, 9>(pw, hs); break;
+                default: window_sum<N, 11>(pw, hs); break;
+            }
+            store_regs<N>(myring + (ry % ringn) * (TX * D2), hs);
         }
-        store_regs<N>(myring + (ry % ringn) * (COST_TX * D2), hs);
     };
 
     const int ylast = H - 1 - radius;
@@ -323,17 +282,19 @@ __global__ __launch_bounds__(256) void k_cost(const uint2* __restrict__ stat_l, 
 #pragma unroll
         for (int k = 0; k < N; k++) acc[k] += hs[k] * mult;
     }
-    uint32_t* Cout = C + (size_t)xl * D2 + q * N;
+    uint32_t* Cout = C + (size_t)min(xl, W1 - 1) * D2 + q * N;
     const size_t rowN = (size_t)W1 * D2;
     for (int y = y0; y < y1; y++) {
         uint32_t out[N];
         if (y <= ylast) {
             if (y > ys) {
                 hs_row(y + radius, hs);
-                uint32_t old[N];
-                load_regs<N>(myring + (max(y - radius - 1, 0) % ringn) * (COST_TX * D2), old);
+                if (j < TX) {
+                    uint32_t old[N];
+                    load_regs<N>(myring + (max(y - radius - 1, 0) % ringn) * (TX * D2), old);
 #pragma unroll
-                for (int k = 0; k < N; k++) acc[k] = acc[k] + hs[k] - old[k];
+                    for (int k = 0; k < N; k++) acc[k] = acc[k] + hs[k] - old[k];
+                }
             }
 #pragma unroll
             for (int k = 0; k < N; k++) out[k] = acc[k] + P2P2;
@@ -373,9 +334,6 @@ __device__ __forceinline__ UniqK make_uniq(int uniq) {
     u.mul = 100 - uniq;
     u.magic = u.mul > 0 ? 0xFFFFFFFFu / (uint32_t)u.mul + 1u : 0u;
     return u;
-}
-__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {  // each half = max(a - b, 0)
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
 
 template <int N>
@@ -457,8 +415,8 @@ struct AggBatch {
 // store S at all; the finished S of the pixel is still in registers, so WTA runs right here and
 // only the 8-byte WTA record leaves the kernel (saves one volume write and one volume read).
 template <int N, bool VERT, int MODE, int U>
-__global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, int W1, int H, int dx,
-                                             int dy, uint32_t P1P1, uint32_t P2P2, uint2* __restrict__ rec, int uniq) {
+__device__ __forceinline__ void agg_body(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, int W1, int H, int dx, int dy,
+                                         uint32_t P1P1, uint32_t P2P2, uint2* __restrict__ rec, int uniq) {
     constexpr bool FIRST = (MODE & 1) != 0, LAST = (MODE & 2) != 0;
     const int W = W1 + 32 * N;
     const int q = threadIdx.x & 15;
@@ -582,6 +540,34 @@ __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint
             for (int k = 0; k < N; k++) s[k] = 0;
         }
         step(c, s, off, (uint32_t)(y * W + x + 32 * N), fresh);
+    }
+}
+
+template <int N, bool VERT, int MODE, int U>
+__global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, int W1, int H, int dx,
+                                             int dy, uint32_t P1P1, uint32_t P2P2, uint2* __restrict__ rec, int uniq) {
+    agg_body<N, VERT, MODE, U>(C, S, W1, H, dx, dy, P1P1, P2P2, rec, uniq);
+}
+
+// All paths of a small batch in ONE launch: blockIdx.z picks the path, every path writes its own L
+// volume (FIRST mode).  A single 640x480 frame is then 8 x 128 waves in flight instead of 128 (the
+// card has 1024 SIMDs; eight streams do not help, only four hardware queues exist per process).
+struct PathSet {
+    uint32_t* L[8];
+    signed char dx[8], dy[8];
+};
+template <int N, int U>
+__global__ __launch_bounds__(64) void k_agg_paths(const uint32_t* __restrict__ C, PathSet ps, int W1, int H, uint32_t P1P1,
+                                                   uint32_t P2P2) {
+    const int path = blockIdx.z;
+    const int dx = ps.dx[path], dy = ps.dy[path];
+    uint32_t* L = ps.L[path];
+    if (dy != 0) {
+        if ((int)(blockIdx.x * 4) >= W1) return;  // the grid is sized for the longer of the two chain counts
+        agg_body<N, true, 1, U>(C, L, W1, H, dx, dy, P1P1, P2P2, nullptr, 0);
+    } else {
+        if ((int)(blockIdx.x * 4) >= H) return;
+        agg_body<N, false, 1, U>(C, L, W1, H, dx, dy, P1P1, P2P2, nullptr, 0);
     }
 }
 
