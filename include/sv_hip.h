@@ -141,6 +141,18 @@ int sv_compute_gray_host(sv_ctx* ctx, const uint8_t* left_host, size_t left_stri
                          const uint8_t* right_host, size_t right_stride,
                          int16_t* disp16_host, size_t disp_stride);
 
+/* The same, asynchronously: sv_submit_gray_host stages the pair in pinned memory,
+ * enqueues upload + matcher + download on the context stream and returns a
+ * ticket at once; sv_wait_host blocks until that pair is done and copies its
+ * disparity16 out.  Up to SV_MAX_IN_FLIGHT pairs may be in flight, so the
+ * copies and the host side of frame i+1 overlap the kernels of frame i (the
+ * reference blocks on every copy and kernel, bova_sgm.cu:87-136).  Tickets
+ * must be waited for in the order they were issued.                           */
+#define SV_MAX_IN_FLIGHT 8
+int sv_submit_gray_host(sv_ctx* ctx, const uint8_t* left_host, size_t left_stride,
+                        const uint8_t* right_host, size_t right_stride, int* ticket);
+int sv_wait_host(sv_ctx* ctx, int ticket, int16_t* disp16_host, size_t disp_stride);
+
 /* Same path with inputs and output already resident in HBM (dense rows:
  * stride = width resp. 2*width bytes).  Asynchronous on the context stream.   */
 int sv_compute_gray_dev(sv_ctx* ctx, const uint8_t* left_dev, const uint8_t* right_dev,

@@ -23,3 +23,19 @@ for sp in (0,50):
     lt=torch.from_numpy(l).cuda(); rt=torch.from_numpy(r).cuda(); out=torch.empty((H,W),dtype=torch.int16,device='cuda')
     print("  compute_gray dev %.3f ms"%t(lambda:m.compute_gray_dev(lt,rt,out)))
     m.close()
+
+p=svhip.default_params(D,8)
+m=svhip.Matcher(W,H,p)
+import collections
+def pipe(n=200, depth=6):
+    q=collections.deque(); done=0
+    t0=time.perf_counter()
+    for i in range(n):
+        if len(q)==depth: m.wait(q.popleft()); done+=1
+        q.append(m.submit_gray(l,r))
+    while q: m.wait(q.popleft())
+    return n/(time.perf_counter()-t0)
+pipe(20)
+for d in (1,2,4,7): print("async host pipeline depth %d: %.0f fps"%(d,pipe(300,d)))
+print("synchronous host: %.0f fps"%(1e3/t(lambda:m.compute_gray(l,r))))
+m.close()

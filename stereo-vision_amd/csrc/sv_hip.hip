@@ -43,6 +43,17 @@ struct sv_ctx {
     Buf rec;                 // WTA records {disp16, raw, minS, 0} [H][W] x 8 bytes
     bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
     bool force_fuse = false; // sv_set_debug(ctx, 2): WTA fused into the last path whatever the batch size
+    // asynchronous host-buffer pipeline (sv_submit_gray_host / sv_wait_host): pinned staging slots
+    static constexpr int N_SLOTS = SV_MAX_IN_FLIGHT;
+    struct Slot {
+        uint8_t* in = nullptr;    // pinned: left image, right image (dense)
+        int16_t* out = nullptr;   // pinned: disparity16 (dense)
+        hipEvent_t done = nullptr;
+        bool busy = false;
+        int rc = 0;
+    } slot[N_SLOTS];
+    bool slots_ok = false;
+    long next_ticket = 0;
     // fused four-path sweeps (sv_sweep.hip.h)
     Buf sw_handoff, sw_progress, sw_sink, sw_prof;
     int sw_prof_n = 0;
@@ -703,6 +714,12 @@ int sv_destroy(sv_ctx* c) {
                           &c->wls_v, &c->wls_o16, &c->wls_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
             for (Buf* b : all) release(*b);
             if (c->sw_error) (void)hipHostFree(c->sw_error);
+            if (c->slots_ok)
+                for (auto& sl : c->slot) {
+                    if (sl.in) (void)hipHostFree(sl.in);
+                    if (sl.out) (void)hipHostFree(sl.out);
+                    if (sl.done) (void)hipEventDestroy(sl.done);
+                }
             for (int i = 0; i < 8; i++) release(c->Lbuf[i]);
 
             if (c->ev_ok)
@@ -783,6 +800,65 @@ int sv_compute_gray_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_
     if ((rc = run_sgm(c, (const uint8_t*)c->img_l.p, (const uint8_t*)c->img_r.p, (int16_t*)c->out.p))) return rc;
     HIPCHK(c, copy2d(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_sweep_error(c);
+}
+
+int sv_submit_gray_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int* ticket) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!left || !right || !ticket) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    const size_t W = c->W, H = c->H;
+    if (ls < W || rs < W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    if (!c->slots_ok) {
+        for (auto& sl : c->slot) {
+            HIPCHK(c, hipHostMalloc((void**)&sl.in, 2 * W * H, hipHostMallocDefault));
+            HIPCHK(c, hipHostMalloc((void**)&sl.out, 2 * W * H, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
+        c->slots_ok = true;
+    }
+    sv_ctx::Slot& sl = c->slot[c->next_ticket % sv_ctx::N_SLOTS];
+    if (sl.busy) return fail(c, SV_ERR_INVALID_ARG, "%d pairs already in flight: sv_wait_host the oldest ticket first", sv_ctx::N_SLOTS);
+    int rc;
+    if ((rc = ensure(c, c->img_l, W * H))) return rc;
+    if ((rc = ensure(c, c->img_r, W * H))) return rc;
+    // into pinned memory: the copies below are then truly asynchronous
+    if (ls == W && rs == W) {
+        memcpy(sl.in, left, W * H);
+        memcpy(sl.in + W * H, right, W * H);
+    } else {
+        for (size_t y = 0; y < H; y++) {
+            memcpy(sl.in + y * W, left + y * ls, W);
+            memcpy(sl.in + (H + y) * W, right + y * rs, W);
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->img_l.p, sl.in, W * H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->img_r.p, sl.in + W * H, W * H, hipMemcpyHostToDevice, c->stream));
+    if ((rc = run_sgm(c, (const uint8_t*)c->img_l.p, (const uint8_t*)c->img_r.p, (int16_t*)c->out.p))) return rc;
+    HIPCHK(c, hipMemcpyAsync(sl.out, c->out.p, 2 * W * H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(sl.done, c->stream));
+    sl.busy = true;
+    *ticket = (int)(c->next_ticket++ & 0x7FFFFFFF);
+    return SV_OK;
+}
+
+int sv_wait_host(sv_ctx* c, int ticket, int16_t* disp16, size_t ds) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!disp16) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    const size_t W = c->W, H = c->H;
+    if (ds < 2 * W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    if (!c->slots_ok || ticket < 0) return fail(c, SV_ERR_INVALID_ARG, "unknown ticket %d", ticket);
+    sv_ctx::Slot& sl = c->slot[ticket % sv_ctx::N_SLOTS];
+    const long newest = c->next_ticket - 1;
+    if (!sl.busy || (long)ticket > (newest & 0x7FFFFFFF) || (newest & 0x7FFFFFFF) - ticket >= sv_ctx::N_SLOTS)
+        return fail(c, SV_ERR_INVALID_ARG, "ticket %d is not in flight", ticket);
+    DevGuard g(c->device);
+    HIPCHK(c, hipEventSynchronize(sl.done));
+    if (ds == 2 * W) memcpy(disp16, sl.out, 2 * W * H);
+    else
+        for (size_t y = 0; y < H; y++) memcpy((char*)disp16 + y * ds, sl.out + y * W, 2 * W);
+    sl.busy = false;
     return check_sweep_error(c);
 }
 

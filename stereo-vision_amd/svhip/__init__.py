@@ -26,7 +26,7 @@ TIMING_NAMES = ("prefilter", "cost", "aggregation", "wta", "tail", "total")
 
 EXPORTS = (
     "sv_default_params", "sv_create", "sv_destroy", "sv_set_params", "sv_get_params", "sv_set_stream",
-    "sv_compute_gray_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
+    "sv_compute_gray_host", "sv_submit_gray_host", "sv_wait_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
     "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host",
@@ -85,6 +85,8 @@ def load():
     L.sv_get_params.argtypes = [vp, C.POINTER(Params)]
     L.sv_set_stream.argtypes = [vp, vp]
     L.sv_compute_gray_host.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    L.sv_submit_gray_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(C.c_int)]
+    L.sv_wait_host.argtypes = [vp, i32, vp, sz]
     L.sv_compute_gray_dev.argtypes = [vp, vp, vp, vp]
     L.sv_set_batch.argtypes = [vp, i32]
     L.sv_compute_gray_batch_dev.argtypes = [vp, i32, vp, vp, vp]
@@ -188,6 +190,20 @@ class Matcher:
         assert left.shape == (self.H, self.W) and right.shape == (self.H, self.W)
         out = np.empty((self.H, self.W), np.int16)
         self._chk(self._L.sv_compute_gray_host(self._h, _ptr(left), self.W, _ptr(right), self.W, _ptr(out), 2 * self.W))
+        return out
+
+    def submit_gray(self, left, right):
+        """Asynchronous compute_gray: returns a ticket for wait()."""
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        assert left.shape == (self.H, self.W) and right.shape == (self.H, self.W)
+        t = C.c_int()
+        self._chk(self._L.sv_submit_gray_host(self._h, _ptr(left), self.W, _ptr(right), self.W, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        out = np.empty((self.H, self.W), np.int16)
+        self._chk(self._L.sv_wait_host(self._h, ticket, _ptr(out), 2 * self.W))
         return out
 
     def upload_maps(self, mlx, mly, mrx, mry):

@@ -122,3 +122,24 @@ def test_full_size_configs_bit_exact(gpu, W, H, D, seed):
     inner = d[16:-16, D + 16:W - k - 16]
     assert (inner == 16 * k).mean() > 0.99
     m.close()
+
+
+def test_async_submit_wait(gpu):
+    """sv_submit_gray_host / sv_wait_host: several pairs in flight, results identical to the
+    synchronous entry point, ring overflow and stale tickets rejected."""
+    W, H, D = 200, 90, 64
+    ph, po = _params(D, 8)
+    pairs = [synth.stereo_pair(60 + i, W, H, D) for i in range(11)]
+    m = svhip.Matcher(W, H, ph)
+    ref = [m.compute_gray(l, r) for l, r, _ in pairs]
+    tickets = [m.submit_gray(pairs[i][0], pairs[i][1]) for i in range(8)]
+    with pytest.raises(svhip.SvError):
+        m.submit_gray(pairs[8][0], pairs[8][1])           # ninth pair: all slots busy
+    for i in range(3):
+        assert np.array_equal(m.wait(tickets[i]), ref[i])
+    tickets += [m.submit_gray(pairs[i][0], pairs[i][1]) for i in range(8, 11)]
+    for i in range(3, 11):
+        assert np.array_equal(m.wait(tickets[i]), ref[i]), i
+    with pytest.raises(svhip.SvError):
+        m.wait(tickets[2])                                 # already collected
+    m.close()
