@@ -245,6 +245,24 @@ int sv_filter_wls_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stri
                        size_t vis_stride, const uint8_t* guide_rgb_host, size_t guide_stride,
                        int16_t* disp16_wls_host, size_t out16_stride, uint8_t* vis_wls_host, size_t out8_stride);
 
+/* Replaces the BLF_ORIGINAL branch of StereoMatcherNew::filterBLF
+ * (StereoMatcher.cpp:90-99): cv_extend::bilateralFilter(input16,
+ * disparity16_blf, sigmaColorBLF, sigmaSpaceBLF), the FP64 bilateral-grid
+ * filter of modules/DisparityModule/fastBilateral.hpp:92-189, followed by
+ * getDisparityVis(disparity16_blf, disparity_blf, 3) when vis_blf != NULL.
+ * Computed in FP64 in the reference's order of operations: bit-exact against
+ * the CPU.  disp16_blf may be the input buffer.  One frame per call; the call
+ * reads the map's min/max back to size the grid (one stream synchronisation).
+ * Grids above 2^27 cells (sigmas near 1 on a large map) are rejected with
+ * SV_ERR_UNSUPPORTED.  BLF_DISABLED needs no call (the reference clones);
+ * BLF_CUDA (cv::cuda::DisparityBilateralFilter, OpenCV-CUDA only) is not
+ * provided.                                                                   */
+int sv_filter_blf_dev(sv_ctx* ctx, const int16_t* disp16_dev, double sigma_color, double sigma_space,
+                      int16_t* disp16_blf_dev, uint8_t* vis_blf_dev);
+int sv_filter_blf_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride, double sigma_color,
+                       double sigma_space, int16_t* disp16_blf_host, size_t out16_stride,
+                       uint8_t* vis_blf_host, size_t out8_stride);
+
 /* Replaces DispModule::depthFromDisparity (DispModule.cpp:320-366), with the
  * non-aliased read.  mapper = MapperL (CV_32FC2,
  * width*height*2 floats; NULL = the device-resident MapperL made by

@@ -11,6 +11,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -18,6 +19,90 @@
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* ---------------------------------------------------------------------------------------------
+ * A16 filterBLF, BLF_ORIGINAL branch (StereoMatcher.cpp:90-99): cv_extend::bilateralFilter on the
+ * 16-bit disparity map, the bilateral-grid filter of modules/DisparityModule/fastBilateral.hpp:92-189
+ * (REPO item: the whole algorithm is in the reference tree, in FP64).  Grid cells hold (sum, count);
+ * here as two planes instead of the reference's interleaved pairs, the arithmetic per component is
+ * the same.  Steps, with the reference's line numbers:
+ *   :120-124 value range and grid size (padding 2 on every side),
+ *   :131-143 splat every pixel into its nearest cell,
+ *   :153-170 [1 2 1]/4 along y, y, x, x, z, z over the interior cells (border cells are never
+ *            written and never receive a splat, so they stay 0),
+ *   :174-177 sum /= count (count 0 -> divide by 1),
+ *   :179-187 trilinear read-back at the pixel's own (y, x, value) position, index + 1 clamped,
+ *   :108-109 convertTo(CV_16S): round half to even, saturate.
+ * Returns 0, or -1 for non-positive sigmas / an allocation failure.
+ * ------------------------------------------------------------------------------------------- */
+static size_t blf_clampi(size_t lo, size_t hi, size_t x) { return x < lo ? lo : (x < hi ? x : hi); }
+
+int svref_blf(const int16_t* src, int W, int H, double sigma_color, double sigma_space, int16_t* dst) {
+    if (!(sigma_color > 0.0) || !(sigma_space > 0.0) || W <= 0 || H <= 0) return -1;
+    const size_t n = (size_t)W * H, pad = 2;
+    double vmin = src[0], vmax = src[0];
+    for (size_t i = 1; i < n; i++) {
+        if (src[i] < vmin) vmin = src[i];
+        if (src[i] > vmax) vmax = src[i];
+    }
+    const size_t gh = (size_t)((double)(size_t)(H - 1) / sigma_space) + 1 + 2 * pad;
+    const size_t gw = (size_t)((double)(size_t)(W - 1) / sigma_space) + 1 + 2 * pad;
+    const size_t gd = (size_t)((vmax - vmin) / sigma_color) + 1 + 2 * pad;
+    const size_t cells = gh * gw * gd;
+    double* g[4]; /* sum, count and their ping-pong partners */
+    for (int i = 0; i < 4; i++) {
+        g[i] = (double*)calloc(cells, sizeof(double));
+        if (!g[i]) { for (int j = 0; j < i; j++) free(g[j]); return -1; }
+    }
+    double *ds = g[0], *dc = g[1], *bs = g[2], *bc = g[3];
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const double v = src[(size_t)y * W + x];
+            const size_t sx = (size_t)((double)x / sigma_space + 0.5) + pad;
+            const size_t sy = (size_t)((double)y / sigma_space + 0.5) + pad;
+            const size_t sz = (size_t)((v - vmin) / sigma_color + 0.5) + pad;
+            const size_t c = (sy * gw + sx) * gd + sz;
+            ds[c] += v;
+            dc[c] += 1.0;
+        }
+    const ptrdiff_t offs[3] = {(ptrdiff_t)(gw * gd), (ptrdiff_t)gd, 1};
+    for (int dim = 0; dim < 3; dim++)
+        for (int it = 0; it < 2; it++) {
+            double* t;
+            t = ds; ds = bs; bs = t;
+            t = dc; dc = bc; bc = t;
+            const ptrdiff_t off = offs[dim];
+            for (size_t y = 1; y + 1 < gh; y++)
+                for (size_t x = 1; x + 1 < gw; x++)
+                    for (size_t z = 1; z + 1 < gd; z++) {
+                        const size_t c = (y * gw + x) * gd + z;
+                        ds[c] = (bs[c - off] + bs[c + off] + 2.0 * bs[c]) / 4.0;
+                        dc[c] = (bc[c - off] + bc[c + off] + 2.0 * bc[c]) / 4.0;
+                    }
+        }
+    for (size_t c = 0; c < cells; c++) ds[c] /= dc[c] != 0 ? dc[c] : 1;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const double z = (double)src[(size_t)y * W + x] - vmin;
+            const double px = (double)x / sigma_space + (double)pad;
+            const double py = (double)y / sigma_space + (double)pad;
+            const double pz = z / sigma_color + (double)pad;
+            const size_t y0 = blf_clampi(0, gh - 1, (size_t)py), y1 = blf_clampi(0, gh - 1, y0 + 1);
+            const size_t x0 = blf_clampi(0, gw - 1, (size_t)px), x1 = blf_clampi(0, gw - 1, x0 + 1);
+            const size_t z0 = blf_clampi(0, gd - 1, (size_t)pz), z1 = blf_clampi(0, gd - 1, z0 + 1);
+            const double ya = py - (double)y0, xa = px - (double)x0, za = pz - (double)z0;
+#define G(yy, xx, zz) ds[((yy) * gw + (xx)) * gd + (zz)]
+            const double r = (1.0 - ya) * (1.0 - xa) * (1.0 - za) * G(y0, x0, z0) + (1.0 - ya) * xa * (1.0 - za) * G(y0, x1, z0) +
+                             ya * (1.0 - xa) * (1.0 - za) * G(y1, x0, z0) + ya * xa * (1.0 - za) * G(y1, x1, z0) +
+                             (1.0 - ya) * (1.0 - xa) * za * G(y0, x0, z1) + (1.0 - ya) * xa * za * G(y0, x1, z1) +
+                             ya * (1.0 - xa) * za * G(y1, x0, z1) + ya * xa * za * G(y1, x1, z1);
+#undef G
+            const double q = nearbyint(r); /* cvRound: ties to even under the default rounding mode */
+            dst[(size_t)y * W + x] = (int16_t)(q < -32768.0 ? -32768.0 : (q > 32767.0 ? 32767.0 : q));
+        }
+    for (int i = 0; i < 4; i++) free(g[i]);
+    return 0;
+}
 
 const char* svref_version(void) { return "sv_ref 1 (restated SGBM, parity unpinned)"; }
 

@@ -113,6 +113,9 @@ int svref_init_rectify_map(const double* K, const double* dist, const double* R,
 int svref_undistort_grid(const double* K, const double* dist, const double* R, const double* P, int W, int H,
                          float* mapper);
 
+/* A16 filterBLF / BLF_ORIGINAL: cv_extend::bilateralFilter (fastBilateral.hpp:92-189, in the reference tree) */
+int svref_blf(const int16_t* src, int W, int H, double sigma_color, double sigma_space, int16_t* dst);
+
 const char* svref_version(void);
 #ifdef __cplusplus
 }

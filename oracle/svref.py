@@ -97,6 +97,8 @@ def lib():
                                 C.c_int]
         L.svref_wls_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int * 4),
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.svref_blf.restype = C.c_int
+        L.svref_blf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.svref_init_rectify_map.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.svref_undistort_grid.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]
         _lib = L
@@ -290,3 +292,12 @@ def undistort_grid(K, dist, R, P, W, H):
     if rc:
         raise ValueError("svref_undistort_grid failed: %d" % rc)
     return out
+
+
+def blf(disp16, sigma_color, sigma_space):
+    """filterBLF / BLF_ORIGINAL: cv_extend::bilateralFilter on a 16-bit disparity map."""
+    src = np.ascontiguousarray(disp16, dtype=np.int16)
+    dst = np.empty_like(src)
+    if lib().svref_blf(_ptr(src), src.shape[1], src.shape[0], float(sigma_color), float(sigma_space), _ptr(dst)) != 0:
+        raise ValueError("svref_blf: bad arguments")
+    return dst

@@ -18,6 +18,7 @@
 
 #include "sv_kernels.hip.h"
 #include "sv_sweep.hip.h"
+#include "sv_blf.hip.h"
 
 namespace {
 
@@ -82,6 +83,7 @@ struct sv_ctx {
     Buf lab, cnt;            // int [H][W] speckle union-find
     Buf wls_lut, wls_wh, wls_wv, wls_cur, wls_tmp;  // WLS: weight table, edge weights, work images (float)
     Buf wls_g, wls_v, wls_o16, wls_o8;              // WLS host entry point staging
+    Buf blf_a, blf_b, blf_mm, blf_o16, blf_o8;      // BLF: the two grids, min/max words, host entry point staging
     float wls_lut_sigma = -1.0f;                    // sigma the device table was built for
     bool have_maps = false;  // both cameras
     bool have_map[2] = {false, false};
@@ -711,7 +713,7 @@ int sv_destroy(sv_ctx* c) {
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->mapper_lr[0], &c->mapper_lr[1], &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt, &c->wls_lut, &c->wls_wh, &c->wls_wv, &c->wls_cur, &c->wls_tmp, &c->wls_g,
-                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
+                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->blf_a, &c->blf_b, &c->blf_mm, &c->blf_o16, &c->blf_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
             for (Buf* b : all) release(*b);
             if (c->sw_error) (void)hipHostFree(c->sw_error);
             if (c->slots_ok)
@@ -1123,6 +1125,89 @@ int sv_filter_wls_host(sv_ctx* c, const int16_t* d16, size_t ds, const uint8_t* 
         return rc;
     HIPCHK(c, copy2d(out16, os16, c->wls_o16.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     if (vis) HIPCHK(c, copy2d(out8, os8, c->wls_o8.p, W, W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+// filterBLF / BLF_ORIGINAL on the device (kernels and numerics: sv_blf.hip.h).  The grid's depth
+// depends on the value range of the map, so the min/max pass is followed by one small read-back.
+static int blf_dev(sv_ctx* c, const int16_t* d16, double sigma_color, double sigma_space, int16_t* out16, uint8_t* out8) {
+    const int W = c->W, H = c->H;
+    const size_t n = (size_t)W * H;
+    int rc;
+    if ((rc = ensure(c, c->blf_mm, 2 * sizeof(int)))) return rc;
+    int mm[2] = {32767, -32768};
+    HIPCHK(c, hipMemcpyAsync(c->blf_mm.p, mm, sizeof(mm), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(svk::k_blf_minmax, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, c->stream, d16, n,
+                       (int*)c->blf_mm.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(mm, c->blf_mm.p, sizeof(mm), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    svk::BlfGrid g;
+    g.vmin = mm[0];
+    g.sigma_color = sigma_color;
+    g.sigma_space = sigma_space;
+    // fastBilateral.hpp:122-124 (the depth's padding term is written with padding_xy there; both are 2)
+    const size_t gh = (size_t)((double)(size_t)(H - 1) / sigma_space) + 1 + 2 * svk::BLF_PAD;
+    const size_t gw = (size_t)((double)(size_t)(W - 1) / sigma_space) + 1 + 2 * svk::BLF_PAD;
+    const size_t gd = (size_t)(((double)mm[1] - (double)mm[0]) / sigma_color) + 1 + 2 * svk::BLF_PAD;
+    const size_t cells = gh * gw * gd;
+    if (cells > ((size_t)1 << 27))  // 2 grids x 16 B x 2^27 cells = 4 GiB
+        return fail(c, SV_ERR_UNSUPPORTED, "bilateral grid %zux%zux%zu too large: raise sigmaColorBLF / sigmaSpaceBLF", gh, gw, gd);
+    g.gh = (int)gh; g.gw = (int)gw; g.gd = (int)gd;
+    const size_t gbytes = cells * sizeof(double2);
+    if ((rc = ensure(c, c->blf_a, gbytes))) return rc;
+    if ((rc = ensure(c, c->blf_b, gbytes))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->blf_a.p, 0, gbytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->blf_b.p, 0, gbytes, c->stream));
+    double2* data = (double2*)c->blf_a.p;
+    double2* buffer = (double2*)c->blf_b.p;
+    hipLaunchKernelGGL(svk::k_blf_splat, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d16, W, H, g, data);
+    HIPCHK(c, hipGetLastError());
+    const long offs[3] = {(long)(gw * gd), (long)gd, 1};
+    for (int dim = 0; dim < 3; dim++)
+        for (int it = 0; it < 2; it++) {
+            std::swap(data, buffer);  // :156
+            hipLaunchKernelGGL(svk::k_blf_blur, dim3((unsigned)((gd - 2 + 255) / 256), (unsigned)(gw - 2), (unsigned)(gh - 2)), dim3(256), 0,
+                               c->stream, buffer, data, g, offs[dim]);
+            HIPCHK(c, hipGetLastError());
+        }
+    hipLaunchKernelGGL(svk::k_blf_slice, dim3((W + 255) / 256, H), dim3(256), 0, c->stream, d16, W, H, g, data, out16);
+    HIPCHK(c, hipGetLastError());
+    if (out8) {  // getDisparityVis(disparity16_blf, disparity_blf, 3), StereoMatcher.cpp:97
+        hipLaunchKernelGGL(svk::k_vis, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, out16, out8, n, 3);
+        HIPCHK(c, hipGetLastError());
+    }
+    return SV_OK;
+}
+
+int sv_filter_blf_dev(sv_ctx* c, const int16_t* d16, double sigma_color, double sigma_space, int16_t* out16, uint8_t* out8) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !out16) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (!(sigma_color > 0.0) || !(sigma_space > 0.0)) return fail(c, SV_ERR_INVALID_ARG, "sigmaColorBLF and sigmaSpaceBLF must be positive");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    return blf_dev(c, d16, sigma_color, sigma_space, out16, out8);
+}
+
+int sv_filter_blf_host(sv_ctx* c, const int16_t* d16, size_t ds, double sigma_color, double sigma_space, int16_t* out16, size_t os16,
+                       uint8_t* out8, size_t os8) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !out16) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (!(sigma_color > 0.0) || !(sigma_space > 0.0)) return fail(c, SV_ERR_INVALID_ARG, "sigmaColorBLF and sigmaSpaceBLF must be positive");
+    const size_t W = c->W, H = c->H;
+    if (ds < 2 * W || os16 < 2 * W || (out8 && os8 < W)) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    int rc;
+    if ((rc = ensure(c, c->d16tmp, W * H * 2))) return rc;
+    if ((rc = ensure(c, c->blf_o16, W * H * 2))) return rc;
+    if (out8 && (rc = ensure(c, c->blf_o8, W * H))) return rc;
+    HIPCHK(c, copy2d(c->d16tmp.p, 2 * W, d16, ds, 2 * W, H, hipMemcpyHostToDevice, c->stream));
+    if ((rc = blf_dev(c, (const int16_t*)c->d16tmp.p, sigma_color, sigma_space, (int16_t*)c->blf_o16.p, out8 ? (uint8_t*)c->blf_o8.p : nullptr)))
+        return rc;
+    HIPCHK(c, copy2d(out16, os16, c->blf_o16.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    if (out8) HIPCHK(c, copy2d(out8, os8, c->blf_o8.p, W, W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }

@@ -113,10 +113,34 @@ void StereoMatcherNew::matchSGBMHIP() {
 }
 
 void StereoMatcherNew::filterBLF(std::string kind) {
-    if (stereo_parameters.BLFfiltering != BLF_DISABLED)
-        std::cout << "[StereoMatcherNew] !! bilateral filtering is not part of the sgbm_hip build, passing through." << std::endl;
-    disparity_blf = getDisparity(kind).clone();      // StereoMatcher.cpp:117-122
-    disparity16_blf = getDisparity16(kind).clone();
+    Image input = getDisparity(kind);
+    Image input16 = getDisparity16(kind);
+    switch (stereo_parameters.BLFfiltering) {
+        case BLF_ORIGINAL: {
+            // StereoMatcher.cpp:90-99: cv_extend::bilateralFilter on the 16-bit map + getDisparityVis(.,.,3)
+            if (!ctx || input16.empty()) break;
+            Image out16(input16.rows, input16.cols, 1, 2), out8(input16.rows, input16.cols, 1, 1);
+            last_rc = sv_filter_blf_host(ctx, input16.ptr<int16_t>(), input16.step(), stereo_parameters.sigmaColorBLF,
+                                         stereo_parameters.sigmaSpaceBLF, out16.ptr<int16_t>(), out16.step(), out8.ptr<uint8_t>(),
+                                         out8.step());
+            if (last_rc != 0) {
+                std::cout << "[StereoMatcherNew] !! sv_filter_blf_host failed: " << sv_last_error(ctx) << std::endl;
+                break;  // pass the input through, as the disabled branch does
+            }
+            disparity_blf = out8;
+            disparity16_blf = out16;
+            return;
+        }
+        case BLF_CUDA:
+            // StereoMatcher.cpp:101-116 is cv::cuda::DisparityBilateralFilter (OpenCV-CUDA only)
+            std::cout << "[StereoMatcherNew] !! BLF_CUDA needs OpenCV-CUDA and is not part of the sgbm_hip build, passing through." << std::endl;
+            break;
+        case BLF_DISABLED:
+        default:
+            break;
+    }
+    disparity_blf = input.clone();      // StereoMatcher.cpp:117-122
+    disparity16_blf = input16.clone();
 }
 
 void StereoMatcherNew::filterWLS(std::string kind) {
