@@ -273,6 +273,22 @@ int sv_depth_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride,
 int sv_depth_dev(sv_ctx* ctx, const int16_t* disp16_dev, const float* mapper_dev, const double* Q,
                  const double* R, float* depth_dev);
 
+/* Replaces the per-pixel loop of SFM::fillWorld3D (modules/SFM/SFM.cpp:
+ * 1284-1347), i.e. DispModule::get3DPoints(u, v, "ROOT") (DispModule.cpp:
+ * 1103-1160) for every pixel of the ORIGINAL left view: the cartesian image
+ * (x, y, z in the root frame) and the cylindrical one (sqrt(x^2+y^2),
+ * atan2(y, x), z), each width*height*3 floats (ImageOf<PixelRgbFloat>).
+ * Pixels that map outside the rectified image or whose z is outside [0, 10] m
+ * are 0.  mapper as in sv_depth_*; Q 4x4, RLrect 3x3 (not transposed: the
+ * call transposes it as the reference does), HL_root 4x4, row-major doubles in
+ * host memory.  FP64 like the reference; the disparity is read as the int16 it
+ * is (SFM.cpp:1321 reads it with at<long>, a defect that is not reproduced).  */
+int sv_world_image_dev(sv_ctx* ctx, const int16_t* disp16_dev, const float* mapper_dev, const double* Q,
+                       const double* RLrect, const double* HL_root, float* cart_dev, float* cyl_dev);
+int sv_world_image_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride, const float* mapper_host,
+                        const double* Q, const double* RLrect, const double* HL_root, float* cart_host,
+                        size_t cart_stride, float* cyl_host, size_t cyl_stride);
+
 /* Stage access for parity tests and profiling (no counterpart in the
  * reference beyond the #if 0 dump blocks, bova_sgm.cu:141-321).  Copies the
  * internal [H][W-D][D] int16 volumes of the LAST sv_compute_* call to host.

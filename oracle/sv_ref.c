@@ -104,6 +104,53 @@ int svref_blf(const int16_t* src, int W, int H, double sigma_color, double sigma
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * the world image SFM::fillWorld3D builds (modules/SFM/SFM.cpp:1284-1347), with
+ * the per-point arithmetic of DispModule::get3DPoints, drive "ROOT" (DispModule.cpp:1103-1160).
+ * For every ORIGINAL left pixel (u, v): (u', v') = MapperL(u, v), rounded half to even; outside the
+ * rectified image -> the pixel stays 0.  d = disp16(v', u') / 16, w = d*Q32 + Q33,
+ * p = ((u'+1)*Q00 + Q03, (v'+1)*Q11 + Q13, Q23) / w (doubles); z > 10 or z < 0 -> stays 0;
+ * P = HL_root * [RLrect^T 0; 0 1] * (p, 1) (no division by P[3], SFM.cpp:1332);
+ * cart = (x, y, z), cyl = (sqrt(x^2 + y^2), atan2(y, x), z), both as float.
+ * Known defect NOT reproduced: SFM.cpp:1321 reads the CV_16SC1 map with at<long> (8 bytes at an
+ * 8-byte-scaled offset); get3DPoints reads the same quantity correctly (cvGet2D, :1129) and that
+ * is what is restated.  cart / cyl: [H][W][3] float.
+ * ------------------------------------------------------------------------------------------- */
+void svref_world_image(const int16_t* disp16, int W, int H, const float* mapper, const double* Q, const double* RLrect,
+                       const double* HL_root, float* cart, float* cyl) {
+    double Hr[16]; /* HL_root * [RLrect^T 0; 0 1] */
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double a = 0.0;
+            for (int k = 0; k < 4; k++) {
+                const double m = (k < 3 && j < 3) ? RLrect[j * 3 + k] : (k == j ? 1.0 : 0.0); /* transposed */
+                a += HL_root[i * 4 + k] * m;
+            }
+            Hr[i * 4 + j] = a;
+        }
+    memset(cart, 0, (size_t)W * H * 3 * sizeof(float));
+    memset(cyl, 0, (size_t)W * H * 3 * sizeof(float));
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            const size_t o = (size_t)v * W + u;
+            const float usign = mapper[2 * o], vsign = mapper[2 * o + 1];
+            const long u_ = lrintf(usign), v_ = lrintf(vsign);
+            if (u_ < 0 || u_ >= W || v_ < 0 || v_ >= H) continue;
+            double x = ((double)usign + 1) * Q[0] + Q[3];
+            double y = ((double)vsign + 1) * Q[5] + Q[7];
+            double z = Q[11];
+            const double disparity = (double)disp16[(size_t)v_ * W + u_] / 16.0;
+            const double w = disparity * Q[14] + Q[15];
+            x /= w; y /= w; z /= w;
+            if (z > 10.0 || z < 0.0) continue;
+            const double X = Hr[0] * x + Hr[1] * y + Hr[2] * z + Hr[3];
+            const double Y = Hr[4] * x + Hr[5] * y + Hr[6] * z + Hr[7];
+            const double Z = Hr[8] * x + Hr[9] * y + Hr[10] * z + Hr[11];
+            cart[3 * o] = (float)X; cart[3 * o + 1] = (float)Y; cart[3 * o + 2] = (float)Z;
+            cyl[3 * o] = (float)sqrt(X * X + Y * Y); cyl[3 * o + 1] = (float)atan2(Y, X); cyl[3 * o + 2] = (float)Z;
+        }
+}
+
 const char* svref_version(void) { return "sv_ref 1 (restated SGBM, parity unpinned)"; }
 
 /* Limits under which every int16 store of the reference is wrap-free, so the

@@ -116,6 +116,10 @@ int svref_undistort_grid(const double* K, const double* dist, const double* R, c
 /* A16 filterBLF / BLF_ORIGINAL: cv_extend::bilateralFilter (fastBilateral.hpp:92-189, in the reference tree) */
 int svref_blf(const int16_t* src, int W, int H, double sigma_color, double sigma_space, int16_t* dst);
 
+/* 8(f)2 world image: SFM.cpp:1284-1347 with the point arithmetic of DispModule.cpp:1103-1160 */
+void svref_world_image(const int16_t* disp16, int W, int H, const float* mapper, const double* Q, const double* RLrect,
+                       const double* HL_root, float* cart, float* cyl);
+
 const char* svref_version(void);
 #ifdef __cplusplus
 }

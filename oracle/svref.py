@@ -97,6 +97,8 @@ def lib():
                                 C.c_int]
         L.svref_wls_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int * 4),
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.svref_world_image.restype = None
+        L.svref_world_image.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
         L.svref_blf.restype = C.c_int
         L.svref_blf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.svref_init_rectify_map.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -301,3 +303,15 @@ def blf(disp16, sigma_color, sigma_space):
     if lib().svref_blf(_ptr(src), src.shape[1], src.shape[0], float(sigma_color), float(sigma_space), _ptr(dst)) != 0:
         raise ValueError("svref_blf: bad arguments")
     return dst
+
+
+def world_image(disp16, mapper, Q, RLrect, HL_root):
+    """SFM::fillWorld3D: (cartesian, cylindrical) [H][W][3] float images of the original left view."""
+    d = np.ascontiguousarray(disp16, dtype=np.int16)
+    H, W = d.shape
+    mp = np.ascontiguousarray(mapper, dtype=np.float32)
+    Qm, Rm, Hm = (np.ascontiguousarray(a, dtype=np.float64) for a in (Q, RLrect, HL_root))
+    cart = np.empty((H, W, 3), np.float32)
+    cyl = np.empty((H, W, 3), np.float32)
+    lib().svref_world_image(_ptr(d), W, H, _ptr(mp), _ptr(Qm), _ptr(Rm), _ptr(Hm), _ptr(cart), _ptr(cyl))
+    return cart, cyl

@@ -83,6 +83,7 @@ struct sv_ctx {
     Buf lab, cnt;            // int [H][W] speckle union-find
     Buf wls_lut, wls_wh, wls_wv, wls_cur, wls_tmp;  // WLS: weight table, edge weights, work images (float)
     Buf wls_g, wls_v, wls_o16, wls_o8;              // WLS host entry point staging
+    Buf world_cart, world_cyl;                      // f32 [H][W][3] staging of sv_world_image_host
     Buf blf_a, blf_b, blf_mm, blf_o16, blf_o8;      // BLF: the two grids, min/max words, host entry point staging
     float wls_lut_sigma = -1.0f;                    // sigma the device table was built for
     bool have_maps = false;  // both cameras
@@ -713,7 +714,7 @@ int sv_destroy(sv_ctx* c) {
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->mapper_lr[0], &c->mapper_lr[1], &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt, &c->wls_lut, &c->wls_wh, &c->wls_wv, &c->wls_cur, &c->wls_tmp, &c->wls_g,
-                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->blf_a, &c->blf_b, &c->blf_mm, &c->blf_o16, &c->blf_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
+                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->world_cart, &c->world_cyl, &c->blf_a, &c->blf_b, &c->blf_mm, &c->blf_o16, &c->blf_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
             for (Buf* b : all) release(*b);
             if (c->sw_error) (void)hipHostFree(c->sw_error);
             if (c->slots_ok)
@@ -1074,6 +1075,57 @@ int sv_depth_host(sv_ctx* c, const int16_t* d16, size_t dstride, const float* ma
     }
     if ((rc = sv_depth_dev(c, (const int16_t*)c->d16tmp.p, mdev, Q, R, (float*)c->depth.p))) return rc;
     HIPCHK(c, copy2d(depth, ostride, c->depth.p, 4 * W, 4 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+int sv_world_image_dev(sv_ctx* c, const int16_t* d16, const float* mapper, const double* Q, const double* RLrect, const double* HL_root,
+                       float* cart, float* cyl) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !Q || !RLrect || !HL_root || !cart || !cyl) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (!mapper) {
+        if (!c->have_mapper[0]) return fail(c, SV_ERR_NO_MAPS, "no mapper: pass one or call sv_update_mapper(ctx, 0, ...)");
+        mapper = (const float*)c->mapper_lr[0].p;
+    }
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    svk::WorldCoef k;
+    k.q00 = Q[0]; k.q03 = Q[3]; k.q11 = Q[5]; k.q13 = Q[7]; k.q23 = Q[11]; k.q32 = Q[14]; k.q33 = Q[15];
+    for (int i = 0; i < 3; i++)       // Hrect = HL_root * [RLrect^T 0; 0 1]  (SFM.cpp:1300-1302)
+        for (int j = 0; j < 4; j++) {
+            double a = 0.0;
+            for (int t = 0; t < 4; t++) a += HL_root[i * 4 + t] * ((t < 3 && j < 3) ? RLrect[j * 3 + t] : (t == j ? 1.0 : 0.0));
+            k.Hr[i * 4 + j] = a;
+        }
+    hipLaunchKernelGGL(svk::k_world_image, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream, d16, (const float2*)mapper, cart, cyl,
+                       c->W, c->H, k);
+    HIPCHK(c, hipGetLastError());
+    return SV_OK;
+}
+
+int sv_world_image_host(sv_ctx* c, const int16_t* d16, size_t dstride, const float* mapper, const double* Q, const double* RLrect,
+                        const double* HL_root, float* cart, size_t cart_stride, float* cyl, size_t cyl_stride) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || !Q || !RLrect || !HL_root || !cart || !cyl) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    const size_t W = c->W, H = c->H;
+    if (dstride < 2 * W || cart_stride < 12 * W || cyl_stride < 12 * W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    int rc;
+    if ((rc = ensure(c, c->d16tmp, W * H * 2))) return rc;
+    if ((rc = ensure(c, c->world_cart, W * H * 12))) return rc;
+    if ((rc = ensure(c, c->world_cyl, W * H * 12))) return rc;
+    HIPCHK(c, copy2d(c->d16tmp.p, 2 * W, d16, dstride, 2 * W, H, hipMemcpyHostToDevice, c->stream));
+    const float* mdev = nullptr;  // NULL: the device-resident MapperL of sv_update_mapper
+    if (mapper) {
+        if ((rc = ensure(c, c->mapper, W * H * 8))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->mapper.p, mapper, W * H * 8, hipMemcpyHostToDevice, c->stream));
+        mdev = (const float*)c->mapper.p;
+    }
+    if ((rc = sv_world_image_dev(c, (const int16_t*)c->d16tmp.p, mdev, Q, RLrect, HL_root, (float*)c->world_cart.p, (float*)c->world_cyl.p)))
+        return rc;
+    HIPCHK(c, copy2d(cart, cart_stride, c->world_cart.p, 12 * W, 12 * W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, copy2d(cyl, cyl_stride, c->world_cyl.p, 12 * W, 12 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SV_OK;
 }

@@ -840,6 +840,40 @@ __global__ __launch_bounds__(256) void k_depth(const int16_t* __restrict__ d16, 
     depth[o] = out;
 }
 
+// SFM::fillWorld3D (modules/SFM/SFM.cpp:1284-1347) with the point arithmetic of
+// DispModule::get3DPoints "ROOT" (DispModule.cpp:1103-1160): cartesian and cylindrical world images
+// of the ORIGINAL left view, FP64 like the reference.  Hr = first three rows of
+// HL_root * [RLrect^T 0; 0 1].  Pixels that map outside the rectified image, or whose z is not in
+// [0, 10] m, are 0 (the reference zeroes both images first).
+struct WorldCoef { double q00, q03, q11, q13, q23, q32, q33, Hr[12]; };
+__global__ __launch_bounds__(256) void k_world_image(const int16_t* __restrict__ d16, const float2* __restrict__ mapper,
+                                                      float* __restrict__ cart, float* __restrict__ cyl, int W, int H, WorldCoef c) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (u >= W) return;
+    const size_t o = (size_t)v * W + u;
+    const float2 m = mapper[o];
+    const float ur = rintf(m.x), vr = rintf(m.y);
+    float cx = 0.f, cy = 0.f, cz = 0.f, rr = 0.f, th = 0.f;
+    if (!(ur < 0 || ur >= (float)W || vr < 0 || vr >= (float)H)) {  // also false for NaN coordinates
+        double x = ((double)m.x + 1) * c.q00 + c.q03;
+        double y = ((double)m.y + 1) * c.q11 + c.q13;
+        double z = c.q23;
+        const double disparity = (double)d16[(size_t)vr * W + (size_t)ur] / 16.0;
+        const double w = disparity * c.q32 + c.q33;
+        x /= w; y /= w; z /= w;
+        if (!(z > 10.0 || z < 0.0)) {
+            const double X = c.Hr[0] * x + c.Hr[1] * y + c.Hr[2] * z + c.Hr[3];
+            const double Y = c.Hr[4] * x + c.Hr[5] * y + c.Hr[6] * z + c.Hr[7];
+            const double Z = c.Hr[8] * x + c.Hr[9] * y + c.Hr[10] * z + c.Hr[11];
+            cx = (float)X; cy = (float)Y; cz = (float)Z;
+            rr = (float)sqrt(X * X + Y * Y);
+            th = (float)atan2(Y, X);
+        }
+    }
+    cart[3 * o] = cx; cart[3 * o + 1] = cy; cart[3 * o + 2] = cz;
+    cyl[3 * o] = rr; cyl[3 * o + 1] = th; cyl[3 * o + 2] = cz;
+}
+
 // ---------------------------------------------------------------------------------------------
 // WLS post-filter.  Result of wls_filter->filter(...) as StereoMatcherNew::filterWLS calls it
 // (StereoMatcher.cpp:154-160) on a filter made by createDisparityWLSFilterGeneric(false) (:265):

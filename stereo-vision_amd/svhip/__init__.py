@@ -29,7 +29,7 @@ EXPORTS = (
     "sv_compute_gray_host", "sv_submit_gray_host", "sv_wait_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
-    "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host",
+    "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_world_image_dev", "sv_world_image_host",
     "sv_synchronize", "sv_last_aggregation", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
     "sv_algorithmic_bytes", "sv_last_error", "sv_version")
@@ -103,6 +103,8 @@ def load():
     L.sv_wls_roi.argtypes = [vp, C.POINTER(C.c_int * 4)]
     L.sv_filter_wls_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.sv_filter_wls_host.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz]
+    L.sv_world_image_dev.argtypes = [vp] * 8
+    L.sv_world_image_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, vp, sz]
     L.sv_filter_blf_dev.argtypes = [vp, vp, C.c_double, C.c_double, vp, vp]
     L.sv_filter_blf_host.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, sz, vp, sz]
     L.sv_init_rectify_map.argtypes = [vp, i32, vp, vp, i32, vp, vp]
@@ -297,6 +299,17 @@ class Matcher:
             self._h, n, C.c_void_p(disp_t.data_ptr()), C.c_void_p(vis_t.data_ptr()) if vis_t is not None else None,
             C.c_void_p(guide_t.data_ptr()), C.c_void_p(out_t.data_ptr()),
             C.c_void_p(vis_out_t.data_ptr()) if vis_out_t is not None else None))
+
+    def world_image(self, disp16, Q, RLrect, HL_root, mapper=None):
+        """SFM::fillWorld3D on host arrays -> (cartesian, cylindrical) [H][W][3] float; mapper None = device MapperL."""
+        d = np.ascontiguousarray(disp16, np.int16)
+        mp = np.ascontiguousarray(mapper, np.float32) if mapper is not None else None
+        Qm, Rm, Hm = (np.ascontiguousarray(a, np.float64) for a in (Q, RLrect, HL_root))
+        cart = np.empty((self.H, self.W, 3), np.float32)
+        cyl = np.empty((self.H, self.W, 3), np.float32)
+        self._chk(self._L.sv_world_image_host(self._h, _ptr(d), 2 * self.W, _ptr(mp) if mp is not None else None, _ptr(Qm), _ptr(Rm),
+                                              _ptr(Hm), _ptr(cart), 12 * self.W, _ptr(cyl), 12 * self.W))
+        return cart, cyl
 
     def filter_blf(self, disp16, sigma_color=10.0, sigma_space=10.0, vis=False):
         """filterBLF / BLF_ORIGINAL on a host array; vis=True also returns getDisparityVis(out, 3)."""
