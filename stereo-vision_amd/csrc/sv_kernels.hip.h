@@ -53,6 +53,13 @@ __device__ __forceinline__ uint32_t row16_or_u32(uint32_t v) {
     v |= dpp<DPP_ROW_MIRROR>(0u, v);
     return v;
 }
+__device__ __forceinline__ uint32_t row16_add_u32(uint32_t v) {
+    v += dpp<DPP_QUAD_XOR1>(0u, v);
+    v += dpp<DPP_QUAD_XOR2>(0u, v);
+    v += dpp<DPP_ROW_HALF_MIRROR>(0u, v);
+    v += dpp<DPP_ROW_MIRROR>(0u, v);
+    return v;
+}
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {  // each half = max(a - b, 0)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
@@ -349,43 +356,46 @@ __device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK
     }
     key = row16_min_u32(key);
     const int minS = (int)(key >> 16), best = (int)(key & 0xFFFFu);
-    // uniqueness: the smallest S outside best-1..best+1 must not be below T
+    // uniqueness: no S outside best-1..best+1 may be below T.  Every S lies in [0, 32767], so with T
+    // clamped to 32768 "S < T" is the sign of the 16-bit difference: count the hits over all
+    // disparities (3 packed instructions per register) and compare with the hits among the three
+    // exempt positions, known once S[best-1] and S[best+1] have been fetched for the sub-pixel step.
     const uint32_t thr = (uint32_t)minS * 100u;
     const uint32_t T = uq.mul > 0 ? __umulhi(thr + (uint32_t)uq.mul - 1u, uq.magic) : (thr > 0u ? 0x10000u : 0u);
+    const uint32_t Tc = min(T, 0x8000u), TT = Tc | (Tc << 16);
+    us2 hits = {0, 0};
+#pragma unroll
+    for (int k = 0; k < N; k++) hits += (__builtin_bit_cast(us2, s[k]) - __builtin_bit_cast(us2, TT)) >> 15;
+    uint32_t cnt = __builtin_bit_cast(uint32_t, hits);
+    cnt = row16_add_u32((cnt & 0xFFFFu) + (cnt >> 16));
+    // S[best-1] and S[best+1]: positions p and p+2 of the owning lane, 0 elsewhere, OR-reduced.
+    // Both have the parity of p and sit in registers kq = p >> 1 and kq + 1 (either may lie outside
+    // this lane: then the neighbouring lane supplies the value).
     const int p = best - 1 - dbase;  // position of best-1 in this lane's 2N values (may lie outside)
-    const uint32_t sh = (uint32_t)(p + 2);
-    const uint32_t bm = sh < 32u ? ((7u << sh) >> 2) : 0u;  // bit i set: position i is one of best-1, best, best+1
-    uint32_t m2 = 0xFFFFFFFFu;
+    const int kq = p >> 1;
+    const uint32_t hsel = (uint32_t)(p & 1) << 4;
+    uint32_t vm = 0u, vp = 0u;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)bm, 2 * k, 1);      // 0 or 0xFFFFFFFF
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)bm, 2 * k + 1, 1);
-        const uint32_t excl = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
-        m2 = pk_min(m2, s[k] | excl);
+        vm = kq == k ? s[k] : vm;
+        vp = kq == k - 1 ? s[k] : vp;
     }
-    m2 = pk_min(m2, __builtin_amdgcn_alignbit(m2, m2, 16));
-    m2 = row16_min_u32(m2 & 0xFFFFu);
-    const bool bad = m2 < T;
-    // S[best-1] and S[best+1]: positions p and p+2 of the owning lane, 0 elsewhere, OR-reduced
-    auto pick = [&](int pos) -> uint32_t {
-        uint32_t v = s[0];
-#pragma unroll
-        for (int k = 1; k < N; k++) v = (pos >> 1) == k ? s[k] : v;
-        v = (pos & 1) ? (v >> 16) : (v & 0xFFFFu);
-        return (uint32_t)pos < (uint32_t)(2 * N) ? v : 0u;
-    };
-    uint32_t nb = (pick(p) << 16) | pick(p + 2);
+    uint32_t nb = (__builtin_amdgcn_ubfe(vm, hsel, 16) << 16) | __builtin_amdgcn_ubfe(vp, hsel, 16);
     nb = row16_or_u32(nb);
     const int sm = (int)(nb >> 16), sp = (int)(nb & 0xFFFFu);
-    // sub-pixel: ((sm - sp)*16 + den) / (2*den), C division (truncation).  |quotient| <= 8, operands
-    // exact in float: a float estimate, then an exact integer correction of +-1.
-    const int den = max(sm + sp - 2 * minS, 1), num = (sm - sp) * 16 + den, den2 = den * 2;
-    int sub = (int)((float)num * __builtin_amdgcn_rcpf((float)den2));  // truncates toward zero
-    int rem = num - sub * den2;
-    // the remainder of a truncating division has the sign of num and magnitude < den2
-    if (rem >= den2 || (num < 0 && rem > 0)) { sub++; rem -= den2; }
-    if (rem <= -den2 || (num >= 0 && rem < 0)) { sub--; rem += den2; }
-    sub = (0 < best && best < D - 1) ? sub : 0;
+    const bool inner = 0 < best && best < D - 1;
+    const uint32_t exempt = (uint32_t)((uint32_t)minS < T) + (uint32_t)(best > 0 && (uint32_t)sm < T) +
+                            (uint32_t)(best < D - 1 && (uint32_t)sp < T);
+    const bool bad = cnt > exempt;
+    // sub-pixel: ((sm - sp)*16 + den) / (2*den), C division (truncation toward zero), |quotient| <= 8.
+    // In float without a correction step: floor(|num| / den2) = floor((2|num| + 1) / (2 den2)), whose
+    // exact value is at least 1/(2 den2) >= 3.8e-6 away from an integer, while v_rcp_f32 + one
+    // multiply are off by at most 8.5 * 1.5 * 2^-23 = 1.5e-6; all operands are exact in float (< 2^24).
+    const int den = max(sm + sp - 2 * minS, 1), num = (sm - sp) * 16 + den;
+    const int sgn = num >> 31;
+    const uint32_t mag = (uint32_t)((num ^ sgn) - sgn);
+    const uint32_t qf = (uint32_t)((float)(2u * mag + 1u) * __builtin_amdgcn_rcpf((float)(4 * den)));
+    const int sub = inner ? (int)((qf ^ (uint32_t)sgn) - (uint32_t)sgn) : 0;
     const bool ok = minS < 32767 && !bad;  // minS == 32767: every S saturated, no minimum
     const int dv = ok ? best * 16 + sub : -16, rw = ok ? best : -1;
     return make_uint2(((uint32_t)dv & 0xFFFFu) | ((uint32_t)rw << 16), (uint32_t)minS);
