@@ -8,6 +8,7 @@
 // packed u16 pairs, neighbours move with DPP row shifts and the per-pixel minimum is a 4-step DPP
 // butterfly, so a step never touches LDS or a barrier.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -195,17 +196,6 @@ __device__ __forceinline__ uint32_t bt_pk2(uint32_t u, uint32_t u0, uint32_t u1,
 // Workgroup barrier that orders LDS traffic only (global loads stay in flight across it).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int N, int TAPS>
-__device__ __forceinline__ void window_sum(const uint32_t* __restrict__ p, uint32_t (&hs)[N]) {
-    uint32_t v[TAPS][N];
-#pragma unroll
-    for (int t = 0; t < TAPS; t++) load_regs<N>(p + t * 16 * N, v[t]);
-#pragma unroll
-    for (int t = 0; t < TAPS; t++)
-#pragma unroll
-        for (int k = 0; k < N; k++) hs[k] += v[t][k];  // <= 189 * 11 per half: no carry
-}
-
 // A workgroup of NT threads owns NT/16 tile columns (TX = NT/16 - 2r output columns + the halo of
 // the horizontal window) x all D and marches down a band of rows.  Thread (j = tid/16, q = tid%16):
 // BT phase: the costs of tile column j for its 2N disparities -> LDS; window phase (j < TX): the
@@ -245,8 +235,9 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
 #pragma unroll
         for (int s6 = 0; s6 < 6; s6++) load_regs<N>(rbase + (size_t)(2 * s6) * plane + (size_t)ry * (WP / 2), rs[s6]);
     };
-    // horizontal box sums of image row ry (operands in lrec / rs) -> hs[N], ring[ry]
-    auto hs_row = [&](int ry, uint32_t (&hs)[N]) {
+    // BT costs of image row ry (operands in lrec / rs, prefetched) -> pix[ry & 1]; then the operands
+    // of the next row are requested.
+    auto bt_store = [&](int ry) {
         const uint32_t ug = (lrec.x & 0xFFu) * 0x10001u, ug0 = ((lrec.x >> 8) & 0xFFu) * 0x10001u;
         const uint32_t ug1 = ((lrec.x >> 16) & 0xFFu) * 0x10001u, ur = (lrec.x >> 24) * 0x10001u;
         const uint32_t ur0 = (lrec.y & 0xFFu) * 0x10001u, ur1 = ((lrec.y >> 8) & 0xFFu) * 0x10001u;
@@ -254,62 +245,82 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
 #pragma unroll
         for (int k = 0; k < N; k++)  // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
             pv[k] = bt_pk2(ug, ug0, ug1, rs[0][k], rs[1][k], rs[2][k]) + ((bt_pk2(ur, ur0, ur1, rs[3][k], rs[4][k], rs[5][k]) >> 2) & 0x3FFF3FFFu);
-        uint32_t* pw = mypix + (ry & 1) * (NCOL * D2);
-        store_regs<N>(pw, pv);
+        store_regs<N>(mypix + (ry & 1) * (NCOL * D2), pv);
         prefetch(ry + 1);
-        // pix[ry & 1] complete; its previous contents (row ry-2) were consumed before the last barrier.
-        // LDS only: __syncthreads() would also wait for the prefetch just issued (vmcnt(0)).
-        lds_barrier();
-#pragma unroll
-        for (int k = 0; k < N; k++) hs[k] = 0;
-        if (j < TX) {
-            // all taps of the window in flight at once (a loop with a run-time trip count waits for
-            // every LDS read before the next: 7 x the LDS latency per row)
-            switch (radius) {
-                case 0: window_sum<N, 1>(pw, hs); break;
-                case 1: window_sum<N, 3>(pw, hs); break;
-                case 2: window_sum<N, 5>(pw, hs); break;
-                case 3: window_sum<N, 7>(pw, hs); break;
-                case 4: window_sum<N, 9>(pw, hs); break;
-                default: window_sum<N, 11>(pw, hs); break;
-            }
-            store_regs<N>(myring + (ry % ringn) * (TX * D2), hs);
-        }
     };
 
     const int ylast = H - 1 - radius;
     const int ys = min(y0, ylast);
-    uint32_t acc[N], hs[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) acc[k] = 0;
-    prefetch(max(ys - radius, 0));
-    for (int ry = max(ys - radius, 0); ry <= ys + radius; ry++) {
-        hs_row(ry, hs);
-        const uint32_t mult = ry == 0 ? (uint32_t)(radius - ys + 1) : 1u;  // row 0 stands for every row above it
-#pragma unroll
-        for (int k = 0; k < N; k++) acc[k] += hs[k] * mult;
-    }
     uint32_t* Cout = C + (size_t)min(xl, W1 - 1) * D2 + q * N;
     const size_t rowN = (size_t)W1 * D2;
-    for (int y = y0; y < y1; y++) {
-        uint32_t out[N];
-        if (y <= ylast) {
-            if (y > ys) {
-                hs_row(y + radius, hs);
-                if (j < TX) {
+    // The rows of the band as a software pipeline, one LDS-only barrier per image row: after the
+    // barrier the window taps of row ry are requested from pix[ry & 1] (all of them in flight: the
+    // tap count is a compile-time constant of the body), the BT costs of row ry + 1 are computed
+    // into the other half while they arrive, then the taps are summed, the row sum goes into the
+    // thread's private ring and the vertical running sum moves one row down.
+    auto run = [&](auto taps_tag) {
+        constexpr int TAPS = decltype(taps_tag)::value;
+        const int r_begin = max(ys - radius, 0), r_init_end = ys + radius;
+        const int r_end = max(min(y1 - 1, ylast), ys) + radius;
+        uint32_t acc[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) acc[k] = 0;
+        prefetch(r_begin);
+        bt_store(r_begin);
+        for (int ry = r_begin; ry <= r_end; ry++) {
+            // pix[ry & 1] complete; its previous contents (row ry-2) were consumed before the last
+            // barrier.  LDS only: __syncthreads() would also wait for the prefetch in flight (vmcnt(0)).
+            lds_barrier();
+            uint32_t v[TAPS][N];
+            const uint32_t* pw = mypix + (ry & 1) * (NCOL * D2);
+            if (j < TX) {
+#pragma unroll
+                for (int t = 0; t < TAPS; t++) load_regs<N>(pw + t * 16 * N, v[t]);
+            }
+            if (ry < r_end) bt_store(ry + 1);
+            if (j < TX) {
+                uint32_t hs[N];
+#pragma unroll
+                for (int k = 0; k < N; k++) hs[k] = 0;
+#pragma unroll
+                for (int t = 0; t < TAPS; t++)
+#pragma unroll
+                    for (int k = 0; k < N; k++) hs[k] += v[t][k];  // <= 189 * 11 per half: no carry
+                store_regs<N>(myring + (ry % ringn) * (TX * D2), hs);
+                if (ry <= r_init_end) {
+                    const uint32_t mult = ry == 0 ? (uint32_t)(radius - ys + 1) : 1u;  // row 0 stands for every row above it
+#pragma unroll
+                    for (int k = 0; k < N; k++) acc[k] += hs[k] * mult;
+                } else {
                     uint32_t old[N];
-                    load_regs<N>(myring + (max(y - radius - 1, 0) % ringn) * (TX * D2), old);
+                    load_regs<N>(myring + (max(ry - 2 * radius - 1, 0) % ringn) * (TX * D2), old);
 #pragma unroll
                     for (int k = 0; k < N; k++) acc[k] = acc[k] + hs[k] - old[k];
                 }
             }
+            const int y = ry - radius;
+            if (ry >= r_init_end && y >= y0 && colok) {
+                uint32_t out[N];
 #pragma unroll
-            for (int k = 0; k < N; k++) out[k] = acc[k] + P2P2;
-        } else {
+                for (int k = 0; k < N; k++) out[k] = acc[k] + P2P2;
+                store_regs<N>(Cout + (size_t)y * rowN, out);
+            }
+        }
+        // the bottom `radius` rows repeat the last computed row (costs.cu:279-282), or hold P2
+        for (int y = max(y0, ylast + 1); y < y1; y++) {
+            uint32_t out[N];
 #pragma unroll
             for (int k = 0; k < N; k++) out[k] = tail_p2 ? P2P2 : acc[k] + P2P2;
+            if (colok) store_regs<N>(Cout + (size_t)y * rowN, out);
         }
-        if (colok) store_regs<N>(Cout + (size_t)y * rowN, out);
+    };
+    switch (radius) {
+        case 0: run(std::integral_constant<int, 1>{}); break;
+        case 1: run(std::integral_constant<int, 3>{}); break;
+        case 2: run(std::integral_constant<int, 5>{}); break;
+        case 3: run(std::integral_constant<int, 7>{}); break;
+        case 4: run(std::integral_constant<int, 9>{}); break;
+        default: run(std::integral_constant<int, 11>{}); break;
     }
 }
 
