@@ -204,18 +204,24 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int N, int NT>
 __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
                                                uint32_t* __restrict__ C, int W, int H, int WP, int radius, int yband,
-                                               uint32_t P2P2, int tail_p2) {
+                                               uint32_t P2P2, int tail_p2, int ntx, int nbands, int nframes) {
     extern __shared__ __align__(16) uint32_t c2_lds[];
     constexpr int D = 32 * N, D2 = 16 * N, NCOL = NT / 16;
     const int W1 = W - D, tid = threadIdx.x, j = tid >> 4, q = tid & 15;
     const int TX = NCOL - 2 * radius, ringn = 2 * radius + 2;
     uint32_t* const pix = c2_lds;                      // [2][NCOL][D2]
     uint32_t* const ring = pix + 2 * NCOL * D2;        // [ringn][TX][D2]
-    const int xl0 = blockIdx.x * TX;
-    const int y0 = blockIdx.y * yband, y1 = min(y0 + yband, H);
-    stat_l += (size_t)blockIdx.z * W * H;
-    const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)blockIdx.z * 12 * H * WP);
-    C += (size_t)blockIdx.z * H * W1 * D2;
+    // 1-D grid, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8
+    // picks the frame within a group of 8 and all column tiles of a frame (whose right-image reads
+    // overlap by D + 2r columns) share one XCD's L2.
+    const int per_frame = ntx * nbands;
+    const int wg = blockIdx.x, fr = (wg / 8 / per_frame) * 8 + (wg & 7), tb = (wg / 8) % per_frame;
+    if (fr >= nframes) return;
+    const int xl0 = (tb % ntx) * TX;
+    const int y0 = (tb / ntx) * yband, y1 = min(y0 + yband, H);
+    stat_l += (size_t)fr * W * H;
+    const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)fr * 12 * H * WP);
+    C += (size_t)fr * H * W1 * D2;
     // BT item of this thread: tile column j (clamped into the computable band), disparities 2N*q ..
     const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + D;
     const int e = (W - 1 - xj) + 2 * N * q;            // reversed index of x - d for the first disparity
