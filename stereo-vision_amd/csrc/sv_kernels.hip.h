@@ -44,8 +44,12 @@ __device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
     v = min(v, dpp<DPP_QUAD_XOR1>(0xFFFFFFFFu, v));
     v = min(v, dpp<DPP_QUAD_XOR2>(0xFFFFFFFFu, v));
     v = min(v, dpp<DPP_ROW_HALF_MIRROR>(0xFFFFFFFFu, v));
-    v = min(v, dpp<DPP_ROW_MIRROR>(0xFFFFFFFFu, v));
-    return v;
+    // Last stage by hand: when its consumer sits in another basic block the compiler leaves this
+    // stage as v_mov -1 + v_mov_dpp + v_min (three instructions).  Every lane has a mirror partner,
+    // so no `old` value is needed; s_nop 1 = the two wait states between a VALU write and a DPP read.
+    uint32_t o;
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    return o;
 }
 __device__ __forceinline__ uint32_t row16_or_u32(uint32_t v) {
     v |= dpp<DPP_QUAD_XOR1>(0u, v);

@@ -59,11 +59,16 @@ __host__ __device__ constexpr size_t sweep_lds_bytes() {
 // One SGM path update of one pixel: r = previous L along the path (0 with dd = P2 when the path
 // starts here), c = the pixel's costs.  Same arithmetic as k_agg's step:
 //   L = C + min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1, dd) - dd  =  C - max(dd - a, 0).
+// edge[0] / edge[1] receive the neighbour lanes' registers through DPP row shifts.  The lane with no
+// neighbour (0 resp. 15 of the row) keeps what the register held before: "no such disparity" =
+// 0x7FFF7FFF, set once before the loop and never overwritten there, so the same register is shifted
+// into every step without being re-initialised (two moves per path and step saved).
 template <int N>
 __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&r)[N], uint32_t dd, uint32_t P1P1,
-                                           uint32_t P2P2, uint32_t (&L)[N], uint32_t& dd_out) {
-    const uint32_t prevHi = dpp<DPP_ROW_SHR1>(0x7FFF7FFFu, r[N - 1]);
-    const uint32_t nextLo = dpp<DPP_ROW_SHL1>(0x7FFF7FFFu, r[0]);
+                                           uint32_t P2P2, uint32_t (&L)[N], uint32_t& dd_out, uint32_t (&edge)[2]) {
+    edge[0] = dpp<DPP_ROW_SHR1>(edge[0], r[N - 1]);
+    edge[1] = dpp<DPP_ROW_SHL1>(edge[1], r[0]);
+    const uint32_t prevHi = edge[0], nextLo = edge[1];
     uint32_t m[N + 1];
     m[0] = __builtin_amdgcn_alignbit(r[0], prevHi, 16);
 #pragma unroll
@@ -150,6 +155,9 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
     for (int k = 0; k < N; k++) r0[k] = dn[k] = dr[0][k] = dr[1][k] = 0;
     const UniqK uqk = make_uniq(a.uniq);
+    uint32_t edge[4][2];  // per path: DPP landing registers of sweep_path
+#pragma unroll
+    for (int k = 0; k < 4; k++) edge[k][0] = edge[k][1] = 0x7FFF7FFFu;
     uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH], recq[SW_DEPTH];
     uint32_t lrbase = 0;                             // index of frame lfi's first WTA record
     const uint32_t rowrec = (uint32_t)yp * a.W + 32 * N, frame_px = (uint32_t)H * a.W;
@@ -216,10 +224,10 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     dd_dl = st_r ? P2P2 : dd_dl;
                 }
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
-                sweep_path<N>(cb[j], r0, dd0, P1P1, P2P2, L0, n0);                   // horizontal
-                sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, P2P2, L1, n1);   // from (x-1, y-1): read two steps ago
-                sweep_path<N>(cb[j], dn, dn_dd, P1P1, P2P2, L2, n2);                 // from (x,   y-1): read last step
-                sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, P2P2, L3, n3);              // from (x+1, y-1): read now
+                sweep_path<N>(cb[j], r0, dd0, P1P1, P2P2, L0, n0, edge[0]);                  // horizontal
+                sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, P2P2, L1, n1, edge[1]);   // from (x-1, y-1): read two steps ago
+                sweep_path<N>(cb[j], dn, dn_dd, P1P1, P2P2, L2, n2, edge[2]);               // from (x,   y-1): read last step
+                sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, P2P2, L3, n3, edge[3]);            // from (x+1, y-1): read now
                 // the parts of this step's record that are used later go straight into their registers
                 load_regs<N>(src + PXW + q * N, dn);
                 load_regs<N>(src + 2 * PXW + q * N, dr[j & 1]);
