@@ -77,6 +77,10 @@ typedef enum sv_status {
 #define SV_FLAG_MEDIAN_REPLICATE 0x08 /* cv::medianBlur border replication instead of unfiltered borders (aggregation.cu:765-767) */
 #define SV_FLAG_NO_LRCHECK 0x10     /* skip the left-right check (disp12MaxDiff < 0 in OpenCV) */
 #define SV_FLAG_NO_MEDIAN 0x20      /* skip the 3x3 median */
+#define SV_FLAG_COST_RGB 0x40       /* matching cost summed over R, G, B: cv::StereoSGBM on the 8UC3 pair, as matchSGBM runs it
+                                      (StereoMatcher.cpp:392-417; P1 = 8*3*SAD^2, P2 = 32*3*SAD^2 are the caller's to set).  Only the
+                                      sv_compute_rgb_* entry points accept it; block sizes whose colour cost would wrap int16
+                                      (> 7 at cap 63) are rejected */
 #define SV_FLAGS_REPO 0x00          /* SGBM5_REPO: bit-faithful to the sgbm_cuda kernels */
 #define SV_FLAGS_HH (SV_FLAG_C_COL0_P2 | SV_FLAG_C_TAIL_P2 | SV_FLAG_LR_OPENCV | SV_FLAG_MEDIAN_REPLICATE)
 

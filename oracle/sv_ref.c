@@ -166,8 +166,9 @@ int svref_check_params(const svref_params* p, int W, int H) {
     if (W <= D || H < BS || W - D < BS) return -1;
     if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63) return -2;
     if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return -2;
-    /* max per-pixel BT cost: 2*cap (gradient channel) + 255>>2 (raw channel) */
-    long cmax = (long)(2 * p->pre_filter_cap + 63) * BS * BS + p->P2;
+    /* max per-pixel BT cost: 2*cap (gradient channel) + 255>>2 (raw channel), per colour channel */
+    const int cn = (p->flags & SVREF_FLAG_COST_RGB) ? 3 : 1;
+    long cmax = (long)cn * (2 * p->pre_filter_cap + 63) * BS * BS + p->P2;
     if (cmax > 32767) return -2;
     if ((long)p->P1 + 32767 > 65535) return -2;
     if (p->uniqueness_ratio < 0 || p->uniqueness_ratio > 100) return -2;
@@ -227,8 +228,21 @@ static void bt_channel(const uint8_t* L, const uint8_t* R, int W, int H, int D, 
 /* A2-A4.  REPO: bova_sgm.cu:94-103 (stage order), costs.cu:203-233 (get_hsum),
  * costs.cu:235-284 (get_cost).  Volumes are [H][W1][D], d innermost, over the
  * computable columns x in [D, W) only. */
+static int cost_volume_planes(const uint8_t* const* lefts, const uint8_t* const* rights, int cn, int W, int H,
+                              const svref_params* p, int16_t* C, svref_stages* st);
+
 int svref_cost_volume(const uint8_t* left, const uint8_t* right, int W, int H, const svref_params* p,
                       int16_t* C, svref_stages* st) {
+    return cost_volume_planes(&left, &right, 1, W, H, p, C, st);
+}
+
+/* cn = 1: the gray path of the CUDA back-end (matchSGBMCUDA).  cn = 3 (EXT): what cv::StereoSGBM does
+ * with the 8UC3 images matchSGBM hands it (StereoMatcher.cpp:392-417): calcPixelCostBT runs the same
+ * prefilter + BT procedure on every colour plane - cn gradient rows with diff_scale 0, then cn raw
+ * rows with diff_scale 2, edge columns of all 2*cn rows forced to tab[0] - and adds the 2*cn costs
+ * into one cost per (x, d).  Stage outputs grad / raw hold the LAST plane. */
+static int cost_volume_planes(const uint8_t* const* lefts, const uint8_t* const* rights, int cn, int W, int H,
+                              const svref_params* p, int16_t* C, svref_stages* st) {
     const int D = p->num_disparities, W1 = W - D, BS = p->block_size, SW2 = BS / 2, SH2 = BS / 2;
     const int P2 = p->P2;
     const size_t npx = (size_t)W * H, nvol = (size_t)W1 * H * D;
@@ -242,10 +256,12 @@ int svref_cost_volume(const uint8_t* left, const uint8_t* right, int W, int H, c
         free(gl); free(gr); free(rl); free(rr); free(pix); free(hs);
         return -6;
     }
-    svref_prefilter(left, W, H, p->pre_filter_cap, gl, rl);
-    svref_prefilter(right, W, H, p->pre_filter_cap, gr, rr);
-    bt_channel(gl, gr, W, H, D, 0, pix); /* bova_sgm.cu:95 */
-    bt_channel(rl, rr, W, H, D, 2, pix); /* bova_sgm.cu:97 */
+    for (int ch = 0; ch < cn; ch++) {
+        svref_prefilter(lefts[ch], W, H, p->pre_filter_cap, gl, rl);
+        svref_prefilter(rights[ch], W, H, p->pre_filter_cap, gr, rr);
+        bt_channel(gl, gr, W, H, D, 0, pix); /* bova_sgm.cu:95 */
+        bt_channel(rl, rr, W, H, D, 2, pix); /* bova_sgm.cu:97 */
+    }
 
     /* A3 horizontal box, costs.cu:214-232 */
     for (int y = 0; y < H; y++) {
@@ -520,15 +536,31 @@ void svref_filter_speckles(int16_t* img, int W, int H, int new_val, int max_size
 
 /* Whole matcher.  Stage order: bova_sgm.cu:87-136; columns [0,D) = -16 (A9);
  * median then speckle as cv::StereoSGBM::compute does (EXT). */
+static int sgbm_planes(const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int cn, int W, int H,
+                       const svref_params* p, int16_t* disp16, size_t ds, svref_stages* st);
+
 int svref_sgbm(const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int W, int H,
                const svref_params* p, int16_t* disp16, size_t ds, svref_stages* st) {
+    if (p && (p->flags & SVREF_FLAG_COST_RGB)) return -2; /* the colour cost needs the RGB entry point */
+    return sgbm_planes(left, ls, right, rs, 1, W, H, p, disp16, ds, st);
+}
+
+/* matchSGBM (StereoMatcher.cpp:392-417): StereoSGBM on the 8UC3 pair, interleaved RGB, strides in bytes */
+int svref_sgbm_rgb(const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int W, int H,
+                   const svref_params* p, int16_t* disp16, size_t ds, svref_stages* st) {
+    if (!p || !(p->flags & SVREF_FLAG_COST_RGB)) return -2;
+    return sgbm_planes(left, ls, right, rs, 3, W, H, p, disp16, ds, st);
+}
+
+static int sgbm_planes(const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int cn, int W, int H,
+                       const svref_params* p, int16_t* disp16, size_t ds, svref_stages* st) {
     int rc = svref_check_params(p, W, H);
     if (rc) return rc;
-    if (!left || !right || !disp16 || ls < (size_t)W || rs < (size_t)W || ds < (size_t)W * 2) return -1;
+    if (!left || !right || !disp16 || ls < (size_t)W * cn || rs < (size_t)W * cn || ds < (size_t)W * 2) return -1;
     const int D = p->num_disparities, W1 = W - D;
     const size_t npx = (size_t)W * H, nvol = (size_t)W1 * H * D;
-    uint8_t* l = (uint8_t*)malloc(npx);
-    uint8_t* r = (uint8_t*)malloc(npx);
+    uint8_t* l = (uint8_t*)malloc(npx * cn); /* cn planes */
+    uint8_t* r = (uint8_t*)malloc(npx * cn);
     int16_t* C = (int16_t*)malloc(nvol * sizeof(int16_t));
     int16_t* S = (int16_t*)calloc(nvol, sizeof(int16_t)); /* cudaMemset, bova_sgm.cu:106 */
     int16_t* disp = (int16_t*)malloc(npx * 2);
@@ -539,11 +571,15 @@ int svref_sgbm(const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, 
         free(l); free(r); free(C); free(S); free(disp); free(raw); free(mins); free(med);
         return -6;
     }
-    for (int y = 0; y < H; y++) {
-        memcpy(l + (size_t)y * W, left + y * ls, W);
-        memcpy(r + (size_t)y * W, right + y * rs, W);
-    }
-    rc = svref_cost_volume(l, r, W, H, p, C, st);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++)
+            for (int ch = 0; ch < cn; ch++) {
+                l[(size_t)ch * npx + (size_t)y * W + x] = left[y * ls + (size_t)x * cn + ch];
+                r[(size_t)ch * npx + (size_t)y * W + x] = right[y * rs + (size_t)x * cn + ch];
+            }
+    const uint8_t* lp[3] = {l, l + npx, l + 2 * npx};
+    const uint8_t* rp[3] = {r, r + npx, r + 2 * npx};
+    rc = cost_volume_planes(lp, rp, cn, W, H, p, C, st);
     if (rc == 0) {
         for (int dir = 0; dir < 8; dir++)
             if (p->path_mask & (1u << dir))

@@ -36,6 +36,7 @@ extern "C" {
 #define SVREF_FLAG_MEDIAN_REPLICATE 0x08
 #define SVREF_FLAG_NO_LRCHECK 0x10
 #define SVREF_FLAG_NO_MEDIAN 0x20
+#define SVREF_FLAG_COST_RGB 0x40 /* cost summed over R, G, B (cv::StereoSGBM on 8UC3, matchSGBM) */
 
 typedef struct svref_params {
     int32_t min_disparity, num_disparities, block_size, P1, P2, pre_filter_cap;
@@ -86,6 +87,11 @@ void svref_filter_speckles(int16_t* img, int W, int H, int new_val, int max_size
 /* whole matcher, gray 8-bit pair -> disparity16; strides in bytes */
 int svref_sgbm(const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int W, int H,
                const svref_params* p, int16_t* disp16, size_t ds, svref_stages* st);
+
+/* matchSGBM (StereoMatcher.cpp:392-417), EXT: the same matcher on interleaved 8UC3 images with the BT
+ * cost of calcPixelCostBT summed over the three colour planes; needs SVREF_FLAG_COST_RGB */
+int svref_sgbm_rgb(const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int W, int H,
+                   const svref_params* p, int16_t* disp16, size_t ds, svref_stages* st);
 
 /* A11 (EXT getDisparityVis) */
 void svref_disparity_vis(const int16_t* disp16, uint8_t* vis, size_t n, int scale);

@@ -17,6 +17,7 @@ INVALID = -16
 PATHS_5, PATHS_8 = 0x1F, 0xFF
 FLAG_C_COL0_P2, FLAG_C_TAIL_P2, FLAG_LR_OPENCV, FLAG_MEDIAN_REPLICATE = 1, 2, 4, 8
 FLAG_NO_LRCHECK, FLAG_NO_MEDIAN = 0x10, 0x20
+FLAG_COST_RGB = 0x40   # cost summed over R, G, B (cv::StereoSGBM on 8UC3 images: matchSGBM)
 FLAGS_REPO = 0
 FLAGS_HH = FLAG_C_COL0_P2 | FLAG_C_TAIL_P2 | FLAG_LR_OPENCV | FLAG_MEDIAN_REPLICATE
 
@@ -69,6 +70,8 @@ def lib():
         L.svref_sgbm.restype = C.c_int
         L.svref_sgbm.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                  C.POINTER(Params), C.c_void_p, C.c_size_t, C.POINTER(Stages)]
+        L.svref_sgbm_rgb.restype = C.c_int
+        L.svref_sgbm_rgb.argtypes = L.svref_sgbm.argtypes
         L.svref_check_params.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
         L.svref_cost_volume.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_void_p,
                                         C.POINTER(Stages)]
@@ -122,7 +125,8 @@ def sgbm(left, right, params, stages=(), path_L=False):
     """Run the oracle.  Returns disp16 [H][W] int16 (and a dict of requested stages)."""
     left = np.ascontiguousarray(left, np.uint8)
     right = np.ascontiguousarray(right, np.uint8)
-    H, W = left.shape
+    rgb = left.ndim == 3          # [H][W][3]: matchSGBM semantics, needs FLAG_COST_RGB in params.flags
+    H, W = left.shape[:2]
     D = params.num_disparities
     out = np.empty((H, W), np.int16)
     st = Stages()
@@ -139,8 +143,10 @@ def sgbm(left, right, params, stages=(), path_L=False):
                 Ls[k] = np.zeros((H, W - D, D), np.int16)
                 st.L[k] = _ptr(Ls[k]).value
         keep["L"] = Ls
-    rc = lib().svref_sgbm(_ptr(left), W, _ptr(right), W, W, H, C.byref(params), _ptr(out), 2 * W,
-                          C.byref(st) if (stages or path_L) else None)
+    fn = lib().svref_sgbm_rgb if rgb else lib().svref_sgbm
+    cn = 3 if rgb else 1
+    rc = fn(_ptr(left), cn * W, _ptr(right), cn * W, W, H, C.byref(params), _ptr(out), 2 * W,
+            C.byref(st) if (stages or path_L) else None)
     if rc != 0:
         raise ValueError("svref_sgbm failed: %d" % rc)
     return (out, keep) if (stages or path_L) else out

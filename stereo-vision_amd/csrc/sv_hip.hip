@@ -61,7 +61,7 @@ struct sv_ctx {
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: 1.5 frames per workgroup pipeline
-    bool attr_sweep[2][4][2] = {}, attr_cost2[8] = {};
+    bool attr_sweep[2][4][2] = {}, attr_cost2[2][8] = {};
     int sweep_cw = 15;                 // compute waves per sweep workgroup (15: one workgroup per CU, 7: two)
     int n_cu = 256;
     // concurrent paths for small batches (run_paths_fanout)
@@ -132,7 +132,8 @@ int check_params(sv_ctx* c, const sv_params* p, int W, int H) {
     if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63)
         return fail(c, SV_ERR_UNSUPPORTED, "pre_filter_cap must be in [1,63] (got %d)", p->pre_filter_cap);
     if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return fail(c, SV_ERR_INVALID_ARG, "need 0 <= P1 <= P2, P2 >= 1");
-    const long cmax = (long)(2 * p->pre_filter_cap + 63) * BS * BS + p->P2;
+    const int cn = (p->flags & SV_FLAG_COST_RGB) ? 3 : 1;
+    const long cmax = (long)cn * (2 * p->pre_filter_cap + 63) * BS * BS + p->P2;
     if (cmax > 32767 || (long)p->P1 + 32767 > 65535)
         return fail(c, SV_ERR_UNSUPPORTED, "cost range overflows int16 (max C = %ld): reduce block_size/P2", cmax);
     if (p->uniqueness_ratio < 0 || p->uniqueness_ratio > 100)
@@ -159,9 +160,10 @@ int alloc_core(sv_ctx* c) {
     const size_t npx = (size_t)c->W * c->H * c->batch;
     const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities * c->batch;
     int rc;
-    if ((rc = ensure(c, c->stat_l, npx * 8))) return rc;
+    const size_t cn = (c->prm.flags & SV_FLAG_COST_RGB) ? 3 : 1;  // statistics per colour plane
+    if ((rc = ensure(c, c->stat_l, npx * 8 * cn))) return rc;
     // right statistics: six u16 planes x two copies (k_stats_planes)
-    if ((rc = ensure(c, c->stat_r, (size_t)12 * c->H * svk::cost_plane_pitch(c->W) * 2 * c->batch))) return rc;
+    if ((rc = ensure(c, c->stat_r, (size_t)12 * c->H * svk::cost_plane_pitch(c->W) * 2 * c->batch * cn))) return rc;
     if ((rc = ensure(c, c->C, nvol * 2))) return rc;
     if ((rc = ensure(c, c->S, nvol * 2))) return rc;
     if ((rc = ensure(c, c->rec, npx * 8))) return rc;
@@ -288,16 +290,17 @@ int run_paths_fanout(sv_ctx* c, int nb) {
     return SV_OK;
 }
 
-template <int N>
+template <int N, int CN>
 int launch_cost2_n(sv_ctx* c, int nb) {
+    // CN = colour planes in the cost: 1 (gray) or 3 (SV_FLAG_COST_RGB)
     constexpr int NT = 512, NCOL = NT / 16;
     const sv_params& p = c->prm;
     const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
     const int TX = NCOL - 2 * r, WP = svk::cost_plane_pitch(W);
     const size_t lds = (size_t)(2 * NCOL + (2 * r + 2) * TX) * (16 * N) * 4;
-    bool* attr_set = c->attr_cost2;  // per context: the attribute is per device
+    bool* attr_set = c->attr_cost2[CN == 3];  // per context: the attribute is per device
     if (lds > 48 * 1024 && !attr_set[N - 1]) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_cost2<N, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_cost2<N, NT, CN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024));
         attr_set[N - 1] = true;
     }
@@ -310,7 +313,7 @@ int launch_cost2_n(sv_ctx* c, int nb) {
     const int nbands = (H + yband - 1) / yband;
     const size_t n_wg = (size_t)ntx * nbands * ((nb + 7) / 8 * 8);
     if (n_wg > 0x7FFFFFFFu) return fail(c, SV_ERR_UNSUPPORTED, "batch too large for one cost launch");
-    hipLaunchKernelGGL((svk::k_cost2<N, NT>), dim3((unsigned)n_wg), dim3(NT), lds, c->stream,
+    hipLaunchKernelGGL((svk::k_cost2<N, NT, CN>), dim3((unsigned)n_wg), dim3(NT), lds, c->stream,
                        (const uint2*)c->stat_l.p, (const uint16_t*)c->stat_r.p, (uint32_t*)c->C.p, W, H, WP, r, yband,
                        (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0, ntx, nbands, nb);
     if (H > 1)
@@ -319,15 +322,16 @@ int launch_cost2_n(sv_ctx* c, int nb) {
     return SV_OK;
 }
 int launch_cost2(sv_ctx* c, int nb) {
+    const bool rgb = (c->prm.flags & SV_FLAG_COST_RGB) != 0;
     switch (c->prm.num_disparities / 32) {
-        case 1: return launch_cost2_n<1>(c, nb);
-        case 2: return launch_cost2_n<2>(c, nb);
-        case 3: return launch_cost2_n<3>(c, nb);
-        case 4: return launch_cost2_n<4>(c, nb);
-        case 5: return launch_cost2_n<5>(c, nb);
-        case 6: return launch_cost2_n<6>(c, nb);
-        case 7: return launch_cost2_n<7>(c, nb);
-        default: return launch_cost2_n<8>(c, nb);
+        case 1: return rgb ? launch_cost2_n<1, 3>(c, nb) : launch_cost2_n<1, 1>(c, nb);
+        case 2: return rgb ? launch_cost2_n<2, 3>(c, nb) : launch_cost2_n<2, 1>(c, nb);
+        case 3: return rgb ? launch_cost2_n<3, 3>(c, nb) : launch_cost2_n<3, 1>(c, nb);
+        case 4: return rgb ? launch_cost2_n<4, 3>(c, nb) : launch_cost2_n<4, 1>(c, nb);
+        case 5: return rgb ? launch_cost2_n<5, 3>(c, nb) : launch_cost2_n<5, 1>(c, nb);
+        case 6: return rgb ? launch_cost2_n<6, 3>(c, nb) : launch_cost2_n<6, 1>(c, nb);
+        case 7: return rgb ? launch_cost2_n<7, 3>(c, nb) : launch_cost2_n<7, 1>(c, nb);
+        default: return rgb ? launch_cost2_n<8, 3>(c, nb) : launch_cost2_n<8, 1>(c, nb);
     }
 }
 template <int N>
@@ -536,9 +540,14 @@ int wls_dev(sv_ctx* c, int nf, const int16_t* d16, const uint8_t* vis, const uin
 }
 
 // The matcher proper: device gray pair -> device disparity16.
-int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp16, int nb = 1) {
+// left / right: gray [nb][H][W], or with SV_FLAG_COST_RGB interleaved RGB [nb][H][W][3] (rgb = true;
+// the two must agree: the gray entry points reject the flag, the RGB ones convert to gray without it)
+int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp16, int nb = 1, bool rgb = false) {
     const sv_params& p = c->prm;
     const int W = c->W, H = c->H, D = p.num_disparities;
+    const int cn = (p.flags & SV_FLAG_COST_RGB) ? 3 : 1;
+    if ((cn == 3) != rgb)
+        return fail(c, SV_ERR_INVALID_ARG, "SV_FLAG_COST_RGB needs the RGB entry points (sv_compute_rgb_*), and only those accept it");
     const bool tm = c->timing && c->ev_ok;
     int e = 0;
     hipEvent_t* evs = c->ev[c->ev_calls % sv_ctx::EV_RING];
@@ -551,8 +560,8 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     const bool fuse = !c->debug && (c->force_fuse || (long)nb * (W - D) >= (long)c->fuse_wta_min_batch * 512);
     mark();
     // 1. prefilter + BT statistics
-    hipLaunchKernelGGL(svk::k_stats_planes, dim3((W + 255) / 256, H, 2 * nb), dim3(256), 0, c->stream, left, right,
-                       (uint2*)c->stat_l.p, (uint16_t*)c->stat_r.p, W, H, svk::cost_plane_pitch(W), p.pre_filter_cap);
+    hipLaunchKernelGGL(svk::k_stats_planes, dim3((W + 255) / 256, H, 2 * nb * cn), dim3(256), 0, c->stream, left, right,
+                       (uint2*)c->stat_l.p, (uint16_t*)c->stat_r.p, W, H, svk::cost_plane_pitch(W), p.pre_filter_cap, cn);
     mark();
     // 2. matching cost volume C
     {
@@ -746,7 +755,8 @@ int sv_set_params(sv_ctx* c, const sv_params* params) {
     if (rc) return rc;
     DevGuard g(c->device);
     if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
-    const bool regeom = params->num_disparities != c->prm.num_disparities;
+    const bool regeom = params->num_disparities != c->prm.num_disparities ||
+                        ((params->flags ^ c->prm.flags) & SV_FLAG_COST_RGB);  // statistics per colour plane
     if (regeom) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->prm = *params;
     return regeom ? alloc_core(c) : SV_OK;
@@ -991,9 +1001,15 @@ int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t
         if ((rc = sv_remap_rgb_dev(c, 0, (const uint8_t*)c->rgb_l.p, (uint8_t*)c->rect_l.p))) return rc;
         if ((rc = sv_remap_rgb_dev(c, 1, (const uint8_t*)c->rgb_r.p, (uint8_t*)c->rect_r.p))) return rc;
     }
-    if ((rc = sv_gray_from_rgb_dev(c, (const uint8_t*)c->rect_l.p, (uint8_t*)c->gray_l.p))) return rc;
-    if ((rc = sv_gray_from_rgb_dev(c, (const uint8_t*)c->rect_r.p, (uint8_t*)c->gray_r.p))) return rc;
-    if ((rc = run_sgm(c, (const uint8_t*)c->gray_l.p, (const uint8_t*)c->gray_r.p, (int16_t*)c->out.p))) return rc;
+    if (c->prm.flags & SV_FLAG_COST_RGB) {
+        // matchSGBM semantics: the matcher runs on the colour pair itself (StereoMatcher.cpp:412)
+        if ((rc = run_sgm(c, (const uint8_t*)c->rect_l.p, (const uint8_t*)c->rect_r.p, (int16_t*)c->out.p, 1, true))) return rc;
+    } else {
+        // matchSGBMCUDA semantics: cvtColor on both images first (StereoMatcher.cpp:429-430)
+        if ((rc = sv_gray_from_rgb_dev(c, (const uint8_t*)c->rect_l.p, (uint8_t*)c->gray_l.p))) return rc;
+        if ((rc = sv_gray_from_rgb_dev(c, (const uint8_t*)c->rect_r.p, (uint8_t*)c->gray_r.p))) return rc;
+        if ((rc = run_sgm(c, (const uint8_t*)c->gray_l.p, (const uint8_t*)c->gray_r.p, (int16_t*)c->out.p))) return rc;
+    }
     HIPCHK(c, copy2d(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_sweep_error(c);

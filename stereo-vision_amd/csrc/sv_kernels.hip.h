@@ -124,17 +124,19 @@ __device__ __forceinline__ void store_regs(uint32_t* __restrict__ p, const uint3
 // clipped Sobel-x value, r the raw channel with its edge columns forced to ftzero, and a0/a1 the
 // min/max of {a, (a+left)/2, (a+right)/2}.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int grad_at(const uint8_t* __restrict__ img, int W, int H, int x, int y, int cap) {
+// ps = pixel stride in bytes (1: gray plane, 3: one channel of an interleaved RGB image)
+__device__ __forceinline__ int grad_at(const uint8_t* __restrict__ img, int W, int H, int x, int y, int cap, int ps) {
     if (x <= 0 || x >= W - 1) return cap;
-    const uint8_t* r0 = img + (size_t)y * W;
-    const uint8_t* rm = img + (size_t)max(y - 1, 0) * W;
-    const uint8_t* rp = img + (size_t)min(y + 1, H - 1) * W;
-    int v = ((int)r0[x + 1] - (int)r0[x - 1]) * 2 + (int)rm[x + 1] - (int)rm[x - 1] + (int)rp[x + 1] - (int)rp[x - 1];
+    const uint8_t* r0 = img + (size_t)y * W * ps;
+    const uint8_t* rm = img + (size_t)max(y - 1, 0) * W * ps;
+    const uint8_t* rp = img + (size_t)min(y + 1, H - 1) * W * ps;
+    const int a = (x + 1) * ps, b = (x - 1) * ps;
+    int v = ((int)r0[a] - (int)r0[b]) * 2 + (int)rm[a] - (int)rm[b] + (int)rp[a] - (int)rp[b];
     return min(max(v, -cap), cap) + cap;
 }
-__device__ __forceinline__ int raw_at(const uint8_t* __restrict__ img, int W, int x, int y, int cap) {
+__device__ __forceinline__ int raw_at(const uint8_t* __restrict__ img, int W, int x, int y, int cap, int ps) {
     if (x <= 0 || x >= W - 1) return cap;
-    return img[(size_t)y * W + x];
+    return img[((size_t)y * W + x) * ps];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -157,29 +159,32 @@ __device__ __forceinline__ int raw_at(const uint8_t* __restrict__ img, int W, in
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline int cost_plane_pitch(int W) { return (W + 2 + 7) & ~7; }
 
+// cn = 1: gray images [frame][H][W].  cn = 3: interleaved RGB [frame][H][W][3]; every colour plane
+// gets its own statistics (blockIdx.z = ((frame * cn + channel) * 2 + is_right)), which is what
+// cv::StereoSGBM's calcPixelCostBT does with 8UC3 input (matchSGBM, StereoMatcher.cpp:392-417).
 __global__ __launch_bounds__(256) void k_stats_planes(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                        uint2* __restrict__ stat_l, uint16_t* __restrict__ rp, int W, int H, int WP,
-                                                       int cap) {
+                                                       int cap, int cn) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
-    const int frame = blockIdx.z >> 1;
+    const int fc = blockIdx.z >> 1, frame = fc / cn, ch = fc - frame * cn;
     const bool is_right = blockIdx.z & 1;
-    const uint8_t* img = (is_right ? right : left) + (size_t)frame * W * H;
-    int g = grad_at(img, W, H, x, y, cap), r = raw_at(img, W, x, y, cap);
-    int gl = x > 0 ? (g + grad_at(img, W, H, x - 1, y, cap)) / 2 : g;
-    int gr = x < W - 1 ? (g + grad_at(img, W, H, x + 1, y, cap)) / 2 : g;
-    int rl = x > 0 ? (r + raw_at(img, W, x - 1, y, cap)) / 2 : r;
-    int rr = x < W - 1 ? (r + raw_at(img, W, x + 1, y, cap)) / 2 : r;
+    const uint8_t* img = (is_right ? right : left) + (size_t)frame * W * H * cn + ch;
+    int g = grad_at(img, W, H, x, y, cap, cn), r = raw_at(img, W, x, y, cap, cn);
+    int gl = x > 0 ? (g + grad_at(img, W, H, x - 1, y, cap, cn)) / 2 : g;
+    int gr = x < W - 1 ? (g + grad_at(img, W, H, x + 1, y, cap, cn)) / 2 : g;
+    int rl = x > 0 ? (r + raw_at(img, W, x - 1, y, cap, cn)) / 2 : r;
+    int rr = x < W - 1 ? (r + raw_at(img, W, x + 1, y, cap, cn)) / 2 : r;
     int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
     int r0 = min(min(rl, rr), r), r1 = max(max(rl, rr), r);
     if (!is_right) {
-        stat_l[(size_t)frame * W * H + (size_t)y * W + x] =
+        stat_l[(size_t)fc * W * H + (size_t)y * W + x] =
             make_uint2((uint32_t)g | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r << 24), (uint32_t)r0 | ((uint32_t)r1 << 8));
     } else {
         const int st[6] = {g, g0, g1, r, r0, r1};
         const int i = W - 1 - x;
-        uint16_t* base = rp + (size_t)frame * 12 * H * WP + (size_t)y * WP;
+        uint16_t* base = rp + (size_t)fc * 12 * H * WP + (size_t)y * WP;
 #pragma unroll
         for (int s6 = 0; s6 < 6; s6++) {
             base[(size_t)(2 * s6) * H * WP + i] = (uint16_t)st[s6];
@@ -205,10 +210,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // BT phase: the costs of tile column j for its 2N disparities -> LDS; window phase (j < TX): the
 // 2r+1-tap horizontal sum for output column j from LDS, the last 2r+2 sums in a private LDS ring,
 // the vertical running sum in registers, C out with the 16-byte stores k_agg / k_sweep read back.
-template <int N, int NT>
+template <int N, int NT, int CN>
 __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
                                                uint32_t* __restrict__ C, int W, int H, int WP, int radius, int yband,
                                                uint32_t P2P2, int tail_p2, int ntx, int nbands, int nframes) {
+    constexpr int cn = CN;  // colour planes summed into the cost (1 = gray, 3 = RGB)
     extern __shared__ __align__(16) uint32_t c2_lds[];
     constexpr int D = 32 * N, D2 = 16 * N, NCOL = NT / 16;
     const int W1 = W - D, tid = threadIdx.x, j = tid >> 4, q = tid & 15;
@@ -223,8 +229,8 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     if (fr >= nframes) return;
     const int xl0 = (tb % ntx) * TX;
     const int y0 = (tb / ntx) * yband, y1 = min(y0 + yband, H);
-    stat_l += (size_t)fr * W * H;
-    const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)fr * 12 * H * WP);
+    stat_l += (size_t)fr * cn * W * H;
+    const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)fr * cn * 12 * H * WP);
     C += (size_t)fr * H * W1 * D2;
     // BT item of this thread: tile column j (clamped into the computable band), disparities 2N*q ..
     const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + D;
@@ -239,24 +245,32 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
 
     uint2 lrec;
     uint32_t rs[6][N];
-    auto prefetch = [&](int ry) {
+    auto prefetch = [&](int ry, int ch) {
         ry = min(ry, H - 1);
-        lrec = stat_l[(size_t)ry * W + xj];
+        lrec = stat_l[(size_t)ch * W * H + (size_t)ry * W + xj];
 #pragma unroll
-        for (int s6 = 0; s6 < 6; s6++) load_regs<N>(rbase + (size_t)(2 * s6) * plane + (size_t)ry * (WP / 2), rs[s6]);
+        for (int s6 = 0; s6 < 6; s6++)
+            load_regs<N>(rbase + (size_t)(12 * ch + 2 * s6) * plane + (size_t)ry * (WP / 2), rs[s6]);
     };
-    // BT costs of image row ry (operands in lrec / rs, prefetched) -> pix[ry & 1]; then the operands
-    // of the next row are requested.
+    // BT costs of image row ry, summed over the cn colour planes (operands of plane 0 in lrec / rs,
+    // prefetched) -> pix[ry & 1]; while a plane is computed the operands of the next plane, or of
+    // plane 0 of the next row, are on their way.
     auto bt_store = [&](int ry) {
-        const uint32_t ug = (lrec.x & 0xFFu) * 0x10001u, ug0 = ((lrec.x >> 8) & 0xFFu) * 0x10001u;
-        const uint32_t ug1 = ((lrec.x >> 16) & 0xFFu) * 0x10001u, ur = (lrec.x >> 24) * 0x10001u;
-        const uint32_t ur0 = (lrec.y & 0xFFu) * 0x10001u, ur1 = ((lrec.y >> 8) & 0xFFu) * 0x10001u;
         uint32_t pv[N];
 #pragma unroll
-        for (int k = 0; k < N; k++)  // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
-            pv[k] = bt_pk2(ug, ug0, ug1, rs[0][k], rs[1][k], rs[2][k]) + ((bt_pk2(ur, ur0, ur1, rs[3][k], rs[4][k], rs[5][k]) >> 2) & 0x3FFF3FFFu);
+        for (int k = 0; k < N; k++) pv[k] = 0;
+#pragma unroll
+        for (int ch = 0; ch < cn; ch++) {
+            const uint32_t ug = (lrec.x & 0xFFu) * 0x10001u, ug0 = ((lrec.x >> 8) & 0xFFu) * 0x10001u;
+            const uint32_t ug1 = ((lrec.x >> 16) & 0xFFu) * 0x10001u, ur = (lrec.x >> 24) * 0x10001u;
+            const uint32_t ur0 = (lrec.y & 0xFFu) * 0x10001u, ur1 = ((lrec.y >> 8) & 0xFFu) * 0x10001u;
+#pragma unroll
+            for (int k = 0; k < N; k++)  // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
+                pv[k] += bt_pk2(ug, ug0, ug1, rs[0][k], rs[1][k], rs[2][k]) + ((bt_pk2(ur, ur0, ur1, rs[3][k], rs[4][k], rs[5][k]) >> 2) & 0x3FFF3FFFu);
+            if (ch + 1 < cn) prefetch(ry, ch + 1);
+            else prefetch(ry + 1, 0);
+        }
         store_regs<N>(mypix + (ry & 1) * (NCOL * D2), pv);
-        prefetch(ry + 1);
     };
 
     const int ylast = H - 1 - radius;
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
         uint32_t acc[N];
 #pragma unroll
         for (int k = 0; k < N; k++) acc[k] = 0;
-        prefetch(r_begin);
+        prefetch(r_begin, 0);
         bt_store(r_begin);
         for (int ry = r_begin; ry <= r_end; ry++) {
             // pix[ry & 1] complete; its previous contents (row ry-2) were consumed before the last

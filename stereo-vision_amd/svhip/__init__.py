@@ -19,6 +19,7 @@ PATH_R, PATH_DR, PATH_D, PATH_DL, PATH_L, PATH_UL, PATH_U, PATH_UR = (1 << i for
 PATHS_5, PATHS_8 = 0x1F, 0xFF
 FLAG_C_COL0_P2, FLAG_C_TAIL_P2, FLAG_LR_OPENCV, FLAG_MEDIAN_REPLICATE = 1, 2, 4, 8
 FLAG_NO_LRCHECK, FLAG_NO_MEDIAN = 0x10, 0x20
+FLAG_COST_RGB = 0x40   # cost summed over R, G, B (cv::StereoSGBM on 8UC3 images: matchSGBM)
 FLAGS_REPO = 0
 FLAGS_HH = FLAG_C_COL0_P2 | FLAG_C_TAIL_P2 | FLAG_LR_OPENCV | FLAG_MEDIAN_REPLICATE
 N_TIMINGS = 6
