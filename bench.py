@@ -35,6 +35,9 @@ CONFIGS = {
     "c1": (320, 240, 64, 8),
     "c2": (640, 480, 128, 8),   # the configuration BASELINE.json's metric is quoted on
     "c4": (1920, 1080, 256, 8),
+    # BASELINE.json configs[2]: rectify remap + SGM + WLS + depth, 640x480, device-resident RGB pairs of
+    # one camera pair (not the headline metric; run with --config c3)
+    "c3": (640, 480, 128, 8),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -139,6 +142,29 @@ def main():
     stream = torch.cuda.current_stream()
     m.set_stream(stream.cuda_stream)
 
+    step = lambda: m.compute_gray_batch_dev(B, lt, rt, out)
+    if args.config == "c3":
+        # full pipeline per frame: remap x2 -> gray x2 -> SGM -> vis -> WLS (16-bit map + vis) -> depth
+        rng = np.random.default_rng(seed0)
+        lrgb = torch.from_numpy(np.stack([synth.rgb_from_gray(rng, lefts[i % n_distinct]) for i in range(B)])).cuda()
+        rrgb = torch.from_numpy(np.stack([synth.rgb_from_gray(rng, rights[i % n_distinct]) for i in range(B)])).cuda()
+        cams = [synth.camera(W, H, i) for i in (0, 1)]
+        for i in (0, 1):   # the synthetic pairs are already row-aligned: both views get the left camera's model
+            m.init_rectify_map(i, *cams[0])
+        m.update_mapper(0, *cams[0])
+        fpx, base = 0.7 * W, 0.068
+        Q = np.array([[1, 0, 0, -(W / 2 - 0.5)], [0, 1, 0, -(H / 2 - 0.5)], [0, 0, 0, fpx], [0, 0, 1 / base, 0]], np.float64)
+        rect = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda")
+        vis = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+        w16, w8 = torch.empty_like(out), torch.empty_like(vis)
+        dep = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+
+        def step():
+            m.compute_rgb_batch_dev(B, lrgb, rrgb, out, rectify=True, rect_left_t=rect)
+            m.disparity_vis_batch_dev(B, out, vis, 3)
+            m.filter_wls_dev(B, out, rect, w16, vis, w8)
+            m.depth_batch_dev(B, w16, Q, cams[0][2], dep)
+
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
@@ -146,12 +172,12 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        m.compute_gray_batch_dev(B, lt, rt, out)
+        step()
     m.enable_timing(True)  # HIP events on the kernels' stream, read back after the timed region
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        m.compute_gray_batch_dev(B, lt, rt, out)
+        step()
     sync_all()
     elapsed = time.perf_counter() - t0
     stage_ms = m.timings()
@@ -184,7 +210,8 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d D=%d %d-path SGM + LR check + median, bit-exact variant SGBM8_HH"
+            "config": {"workload": ("%s: %dx%d D=%d %d-path SGM + LR check + median, bit-exact variant SGBM8_HH"
+                                    + (" inside the full pipeline: rectify remap x2 + gray x2 + SGM + vis + WLS x2 + depth" if args.config == "c3" else ""))
                                    % (args.config, W, H, D, paths),
                        "batch_per_gpu": B, "frames_per_step": world * B, "parallelism": "frame-sharded x%d" % world,
                        "valid_fraction": round(valid, 4)},

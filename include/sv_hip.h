@@ -173,6 +173,17 @@ int sv_set_batch(sv_ctx* ctx, int max_frames);
 int sv_compute_gray_batch_dev(sv_ctx* ctx, int n_frames, const uint8_t* left_dev, const uint8_t* right_dev,
                               int16_t* disp16_dev);
 
+/* The batched form of sv_compute_rgb_host for callers whose images are already on the device (many
+ * frames of one camera pair, e.g. a recorded stream): n_frames dense-packed RGB pairs
+ * ([n][H][W][3] u8) -> [n][H][W] disparity16.  rectify != 0 runs the two cv::remap calls of
+ * StereoCamera::rectifyImages (stereoCamera.cpp:573-574) with the context's maps on every frame;
+ * then cvtColor x2 + the matcher (StereoMatcher.cpp:429-432), or with SV_FLAG_COST_RGB the colour
+ * matcher directly (StereoMatcher.cpp:412).  rect_left_dev: NULL, or a caller-owned [n][H][W][3]
+ * buffer that receives the rectified left images (the guide sv_filter_wls_dev wants).  n_frames <=
+ * the sv_set_batch size.                                                                          */
+int sv_compute_rgb_batch_dev(sv_ctx* ctx, int n_frames, const uint8_t* left_rgb_dev, const uint8_t* right_rgb_dev,
+                             int rectify, uint8_t* rect_left_dev, int16_t* disp16_dev);
+
 /* Replaces the two cv::cvtColor(.., CV_BGR2GRAY) calls of matchSGBMCUDA
  * (StereoMatcher.cpp:429-430) applied to RGB-ordered bytes; 3 bytes/pixel in,
  * 1 byte/pixel out, both on the device.                                       */
@@ -225,6 +236,7 @@ int sv_get_rectified_host(sv_ctx* ctx, int which, uint8_t* rgb_host, size_t stri
 /* Replaces cv::ximgproc::getDisparityVis(disp16, vis, 3)
  * (StereoMatcher.cpp:437): u8 = saturate(round_half_even(disp16*scale/16)).   */
 int sv_disparity_vis_dev(sv_ctx* ctx, const int16_t* disp16_dev, uint8_t* vis_dev, int scale);
+int sv_disparity_vis_batch_dev(sv_ctx* ctx, int n_frames, const int16_t* disp16_dev, uint8_t* vis_dev, int scale);
 int sv_disparity_vis_host(sv_ctx* ctx, const int16_t* disp16_host, uint8_t* vis_host, int scale);
 
 /* Replaces cv::filterSpeckles inside cv::StereoSGBM::compute (called by
@@ -276,6 +288,9 @@ int sv_depth_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride,
                   size_t depth_stride);
 int sv_depth_dev(sv_ctx* ctx, const int16_t* disp16_dev, const float* mapper_dev, const double* Q,
                  const double* R, float* depth_dev);
+/* n_frames dense-packed disparity maps of one camera pair (same mapper, Q, R) in one launch */
+int sv_depth_batch_dev(sv_ctx* ctx, int n_frames, const int16_t* disp16_dev, const float* mapper_dev,
+                       const double* Q, const double* R, float* depth_dev);
 
 /* Replaces the per-pixel loop of SFM::fillWorld3D (modules/SFM/SFM.cpp:
  * 1284-1347), i.e. DispModule::get3DPoints(u, v, "ROOT") (DispModule.cpp:

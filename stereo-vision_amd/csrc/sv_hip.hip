@@ -803,6 +803,46 @@ int sv_compute_gray_batch_dev(sv_ctx* c, int n_frames, const uint8_t* left_dev, 
     return run_sgm(c, left_dev, right_dev, disp16_dev, n_frames);
 }
 
+int sv_compute_rgb_batch_dev(sv_ctx* c, int n_frames, const uint8_t* left, const uint8_t* right, int rectify, uint8_t* rect_left,
+                             int16_t* disp16) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!left || !right || !disp16) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer");
+    if (n_frames < 1 || n_frames > c->batch)
+        return fail(c, SV_ERR_INVALID_ARG, "n_frames %d outside [1, batch=%d] (sv_set_batch)", n_frames, c->batch);
+    if (rectify && !c->have_maps) return fail(c, SV_ERR_NO_MAPS, "rectification maps not uploaded (sv_upload_maps_host / sv_init_rectify_map)");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    const size_t W = c->W, H = c->H, n = n_frames;
+    int rc;
+    const uint8_t *pl = left, *pr = right;
+    if (rectify) {
+        // the two cv::remap calls of rectifyImages (stereoCamera.cpp:573-574), every frame of the batch in one launch
+        if (!rect_left) {
+            if ((rc = ensure(c, c->rect_l, n * W * H * 3))) return rc;
+            rect_left = (uint8_t*)c->rect_l.p;
+        }
+        if ((rc = ensure(c, c->rect_r, n * W * H * 3))) return rc;
+        const dim3 grid((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)n);
+        hipLaunchKernelGGL(svk::k_remap_rgb, grid, dim3(256), 0, c->stream, left, rect_left, (const float*)c->maps[0].p,
+                           (const float*)c->maps[1].p, c->W, c->H);
+        hipLaunchKernelGGL(svk::k_remap_rgb, grid, dim3(256), 0, c->stream, right, (uint8_t*)c->rect_r.p, (const float*)c->maps[2].p,
+                           (const float*)c->maps[3].p, c->W, c->H);
+        HIPCHK(c, hipGetLastError());
+        pl = rect_left;
+        pr = (const uint8_t*)c->rect_r.p;
+    } else if (rect_left) {
+        HIPCHK(c, hipMemcpyAsync(rect_left, left, n * W * H * 3, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (c->prm.flags & SV_FLAG_COST_RGB) return run_sgm(c, pl, pr, disp16, n_frames, true);
+    if ((rc = ensure(c, c->gray_l, n * W * H))) return rc;
+    if ((rc = ensure(c, c->gray_r, n * W * H))) return rc;
+    const size_t npx = n * W * H;
+    hipLaunchKernelGGL(svk::k_gray, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, pl, (uint8_t*)c->gray_l.p, npx);
+    hipLaunchKernelGGL(svk::k_gray, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, pr, (uint8_t*)c->gray_r.p, npx);
+    HIPCHK(c, hipGetLastError());
+    return run_sgm(c, (const uint8_t*)c->gray_l.p, (const uint8_t*)c->gray_r.p, disp16, n_frames);
+}
+
 int sv_compute_gray_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int16_t* disp16, size_t ds) {
     if (!c) return SV_ERR_INVALID_ARG;
     if (!left || !right || !disp16) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer");
@@ -1028,10 +1068,14 @@ int sv_get_rectified_host(sv_ctx* c, int which, uint8_t* rgb, size_t stride) {
 }
 
 int sv_disparity_vis_dev(sv_ctx* c, const int16_t* d16, uint8_t* vis, int scale) {
+    return sv_disparity_vis_batch_dev(c, 1, d16, vis, scale);
+}
+
+int sv_disparity_vis_batch_dev(sv_ctx* c, int n_frames, const int16_t* d16, uint8_t* vis, int scale) {
     if (!c) return SV_ERR_INVALID_ARG;
-    if (!d16 || !vis) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (!d16 || !vis || n_frames < 1) return fail(c, SV_ERR_INVALID_ARG, "bad argument");
     DevGuard g(c->device);
-    const size_t n = (size_t)c->W * c->H;
+    const size_t n = (size_t)c->W * c->H * n_frames;
     hipLaunchKernelGGL(svk::k_vis, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d16, vis, n, scale);
     HIPCHK(c, hipGetLastError());
     return SV_OK;
@@ -1060,8 +1104,13 @@ int sv_filter_speckles_dev(sv_ctx* c, int16_t* d16, int max_size, int max_diff) 
 }
 
 int sv_depth_dev(sv_ctx* c, const int16_t* d16, const float* mapper, const double* Q, const double* R, float* depth) {
+    return sv_depth_batch_dev(c, 1, d16, mapper, Q, R, depth);
+}
+
+int sv_depth_batch_dev(sv_ctx* c, int n_frames, const int16_t* d16, const float* mapper, const double* Q, const double* R,
+                       float* depth) {
     if (!c) return SV_ERR_INVALID_ARG;
-    if (!d16 || !Q || !R || !depth) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (!d16 || !Q || !R || !depth || n_frames < 1 || n_frames > 65535) return fail(c, SV_ERR_INVALID_ARG, "bad argument");
     if (!mapper) {
         if (!c->have_mapper[0]) return fail(c, SV_ERR_NO_MAPS, "no mapper: pass one or call sv_update_mapper(ctx, 0, ...)");
         mapper = (const float*)c->mapper_lr[0].p;
@@ -1071,7 +1120,7 @@ int sv_depth_dev(sv_ctx* c, const int16_t* d16, const float* mapper, const doubl
     k.r02 = (float)R[2]; k.r12 = (float)R[5]; k.r22 = (float)R[8];
     k.q00 = (float)Q[0]; k.q03 = (float)Q[3]; k.q11 = (float)Q[5]; k.q13 = (float)Q[7];
     k.q23 = (float)Q[11]; k.q32 = (float)Q[14]; k.q33 = (float)Q[15];
-    hipLaunchKernelGGL(svk::k_depth, dim3((c->W + 255) / 256, c->H), dim3(256), 0, c->stream, d16, (const float2*)mapper, depth,
+    hipLaunchKernelGGL(svk::k_depth, dim3((c->W + 255) / 256, c->H, n_frames), dim3(256), 0, c->stream, d16, (const float2*)mapper, depth,
                        c->W, c->H, k);
     HIPCHK(c, hipGetLastError());
     return SV_OK;

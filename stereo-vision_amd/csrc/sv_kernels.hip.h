@@ -850,6 +850,8 @@ __global__ __launch_bounds__(256) void k_remap_rgb(const uint8_t* __restrict__ s
                                                     int H) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
+    src += (size_t)blockIdx.z * W * H * 3;  // frames of a batch share the camera's maps
+    dst += (size_t)blockIdx.z * W * H * 3;
     const size_t o = (size_t)y * W + x;
     float fxm = fminf(fmaxf(mapx[o] * 32.0f, -1.0e9f), 1.0e9f);
     float fym = fminf(fmaxf(mapy[o] * 32.0f, -1.0e9f), 1.0e9f);
@@ -873,6 +875,8 @@ __global__ __launch_bounds__(256) void k_depth(const int16_t* __restrict__ d16, 
                                                 float* __restrict__ depth, int W, int H, DepthCoef c) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
     if (v >= W) return;
+    d16 += (size_t)blockIdx.z * W * H;      // frames of a batch share the mapper
+    depth += (size_t)blockIdx.z * W * H;
     const size_t o = (size_t)u * W + v;
     float2 m = mapper[o];
     float usign = rintf(m.x), vsign = rintf(m.y);

@@ -30,7 +30,7 @@ EXPORTS = (
     "sv_compute_gray_host", "sv_submit_gray_host", "sv_wait_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
-    "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_world_image_dev", "sv_world_image_host",
+    "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_compute_rgb_batch_dev", "sv_disparity_vis_batch_dev", "sv_depth_batch_dev", "sv_world_image_dev", "sv_world_image_host",
     "sv_synchronize", "sv_last_aggregation", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
     "sv_algorithmic_bytes", "sv_last_error", "sv_version")
@@ -106,6 +106,9 @@ def load():
     L.sv_filter_wls_host.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz, vp, sz]
     L.sv_world_image_dev.argtypes = [vp] * 8
     L.sv_world_image_host.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, sz, vp, sz]
+    L.sv_compute_rgb_batch_dev.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+    L.sv_disparity_vis_batch_dev.argtypes = [vp, i32, vp, vp, i32]
+    L.sv_depth_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.sv_filter_blf_dev.argtypes = [vp, vp, C.c_double, C.c_double, vp, vp]
     L.sv_filter_blf_host.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, sz, vp, sz]
     L.sv_init_rectify_map.argtypes = [vp, i32, vp, vp, i32, vp, vp]
@@ -311,6 +314,20 @@ class Matcher:
         self._chk(self._L.sv_world_image_host(self._h, _ptr(d), 2 * self.W, _ptr(mp) if mp is not None else None, _ptr(Qm), _ptr(Rm),
                                               _ptr(Hm), _ptr(cart), 12 * self.W, _ptr(cyl), 12 * self.W))
         return cart, cyl
+
+    def compute_rgb_batch_dev(self, n, left_t, right_t, out_t, rectify=True, rect_left_t=None):
+        self._chk(self._L.sv_compute_rgb_batch_dev(
+            self._h, n, C.c_void_p(left_t.data_ptr()), C.c_void_p(right_t.data_ptr()), int(rectify),
+            C.c_void_p(rect_left_t.data_ptr()) if rect_left_t is not None else None, C.c_void_p(out_t.data_ptr())))
+
+    def disparity_vis_batch_dev(self, n, disp_t, vis_t, scale=3):
+        self._chk(self._L.sv_disparity_vis_batch_dev(self._h, n, C.c_void_p(disp_t.data_ptr()), C.c_void_p(vis_t.data_ptr()), scale))
+
+    def depth_batch_dev(self, n, disp_t, Q, R, depth_t, mapper_t=None):
+        Qm, Rm = np.ascontiguousarray(Q, np.float64), np.ascontiguousarray(R, np.float64)
+        self._chk(self._L.sv_depth_batch_dev(self._h, n, C.c_void_p(disp_t.data_ptr()),
+                                             C.c_void_p(mapper_t.data_ptr()) if mapper_t is not None else None,
+                                             _ptr(Qm), _ptr(Rm), C.c_void_p(depth_t.data_ptr())))
 
     def filter_blf(self, disp16, sigma_color=10.0, sigma_space=10.0, vis=False):
         """filterBLF / BLF_ORIGINAL on a host array; vis=True also returns getDisparityVis(out, 3)."""

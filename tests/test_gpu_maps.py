@@ -81,3 +81,51 @@ def test_full_pipeline_with_generated_maps(gpu):
     assert np.quantile(rel, 0.999) <= 1e-4  # a mapper value within 1 ulp of x.5 may round to the other pixel
     assert (dep[fin] != 0).mean() > 0.5
     m.close()
+
+
+def test_batched_full_pipeline_matches_single_frame_calls(gpu):
+    """sv_compute_rgb_batch_dev + sv_disparity_vis_batch_dev + sv_filter_wls_dev + sv_depth_batch_dev on three
+    device-resident frames of one camera pair == the single-frame host entry points frame by frame
+    (which the test above checks against the oracle), for the gray and for the colour cost."""
+    import torch
+    W, H, D, nb = 320, 240, 64, 3
+    rng = np.random.default_rng(4)
+    pairs = [synth.stereo_pair(310 + i, W, H, D) for i in range(nb)]
+    lrgb = np.stack([synth.rgb_from_gray(rng, p[0]) for p in pairs])
+    rrgb = np.stack([synth.rgb_from_gray(rng, p[1]) for p in pairs])
+    cams = [synth.camera(W, H, i) for i in (0, 1)]
+    f, b = 0.7 * W, 0.068
+    Q = np.array([[1, 0, 0, -(W / 2 - 0.5)], [0, 1, 0, -(H / 2 - 0.5)], [0, 0, 0, f], [0, 0, 1 / b, 0]], np.float64)
+    for colour in (False, True):
+        ph = svhip.default_params(D, 8)
+        if colour:
+            ph.P1, ph.P2 = 3 * ph.P1, 3 * ph.P2
+            ph.flags |= svhip.FLAG_COST_RGB
+        m = svhip.Matcher(W, H, ph)
+        for i, cam in enumerate(cams):
+            m.init_rectify_map(i, *cam)
+        m.update_mapper(0, *cams[0])
+        m.set_batch(nb)
+        m.set_stream(torch.cuda.current_stream().cuda_stream)
+        lt, rt = torch.from_numpy(lrgb).cuda(), torch.from_numpy(rrgb).cuda()
+        rect = torch.empty((nb, H, W, 3), dtype=torch.uint8, device="cuda")
+        d16 = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+        vis = torch.empty((nb, H, W), dtype=torch.uint8, device="cuda")
+        w16, w8 = torch.empty_like(d16), torch.empty_like(vis)
+        dep = torch.empty((nb, H, W), dtype=torch.float32, device="cuda")
+        m.compute_rgb_batch_dev(nb, lt, rt, d16, rectify=True, rect_left_t=rect)
+        m.disparity_vis_batch_dev(nb, d16, vis, 3)
+        m.filter_wls_dev(nb, d16, rect, w16, vis, w8)
+        m.depth_batch_dev(nb, w16, Q, cams[0][2], dep)
+        torch.cuda.synchronize()
+        got = [t.cpu().numpy() for t in (rect, d16, vis, w16, w8, dep)]
+        for i in range(nb):
+            e16 = m.compute_rgb(lrgb[i], rrgb[i], rectify=True)
+            assert np.array_equal(got[0][i], m.rectified(0)), (colour, i)
+            assert np.array_equal(got[1][i], e16), (colour, i)
+            e8 = m.disparity_vis(e16, 3)
+            assert np.array_equal(got[2][i], e8)
+            ew16, ew8 = m.filter_wls(e16, vis=e8)
+            assert np.array_equal(got[3][i], ew16) and np.array_equal(got[4][i], ew8)
+            assert np.array_equal(got[5][i], m.depth(ew16, None, Q, cams[0][2]), equal_nan=True)
+        m.close()
