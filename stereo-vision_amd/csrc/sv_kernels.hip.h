@@ -55,15 +55,17 @@ __device__ __forceinline__ uint32_t row16_or_u32(uint32_t v) {
     v |= dpp<DPP_QUAD_XOR1>(0u, v);
     v |= dpp<DPP_QUAD_XOR2>(0u, v);
     v |= dpp<DPP_ROW_HALF_MIRROR>(0u, v);
-    v |= dpp<DPP_ROW_MIRROR>(0u, v);
-    return v;
+    uint32_t o;  // last stage by hand, see row16_min_u32
+    asm("s_nop 1\n\tv_or_b32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    return o;
 }
 __device__ __forceinline__ uint32_t row16_add_u32(uint32_t v) {
     v += dpp<DPP_QUAD_XOR1>(0u, v);
     v += dpp<DPP_QUAD_XOR2>(0u, v);
     v += dpp<DPP_ROW_HALF_MIRROR>(0u, v);
-    v += dpp<DPP_ROW_MIRROR>(0u, v);
-    return v;
+    uint32_t o;
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+    return o;
 }
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {  // each half = max(a - b, 0)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
@@ -378,9 +380,18 @@ __device__ __forceinline__ UniqK make_uniq(int uniq) {
     return u;
 }
 
+// The reductions of one pixel: every lane of the 16-lane group ends up with the same three words.
+struct WtaPart {
+    uint32_t key;  // minS << 16 | min(hits, 255) << 8 | best d; hits = number of disparities with S < T
+    uint32_t nb;   // S[best-1] << 16 | S[best+1] (0 where there is no such disparity)
+};
+__device__ __forceinline__ uint32_t wta_threshold(uint32_t minS, UniqK uq) {
+    const uint32_t thr = minS * 100u;
+    return uq.mul > 0 ? __umulhi(thr + (uint32_t)uq.mul - 1u, uq.magic) : (thr > 0u ? 0x10000u : 0u);
+}
+
 template <int N>
-__device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK uq) {
-    constexpr int D = 32 * N;
+__device__ __forceinline__ WtaPart wta_reduce(const uint32_t (&s)[N], int q, UniqK uq) {
     const int dbase = q * 2 * N;
     // first minimum: packed key (S << 16 | d) under a 32-bit min
     uint32_t key = 0xFFFFFFFFu;
@@ -390,13 +401,12 @@ __device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK
         key = min(key, (s[k] & 0xFFFF0000u) | (uint32_t)(dbase + 2 * k + 1));
     }
     key = row16_min_u32(key);
-    const int minS = (int)(key >> 16), best = (int)(key & 0xFFFFu);
+    const int best = (int)(key & 0xFFFFu);
     // uniqueness: no S outside best-1..best+1 may be below T.  Every S lies in [0, 32767], so with T
     // clamped to 32768 "S < T" is the sign of the 16-bit difference: count the hits over all
-    // disparities (3 packed instructions per register) and compare with the hits among the three
-    // exempt positions, known once S[best-1] and S[best+1] have been fetched for the sub-pixel step.
-    const uint32_t thr = (uint32_t)minS * 100u;
-    const uint32_t T = uq.mul > 0 ? __umulhi(thr + (uint32_t)uq.mul - 1u, uq.magic) : (thr > 0u ? 0x10000u : 0u);
+    // disparities (3 packed instructions per register); wta_finish compares the count with the hits
+    // among the three exempt positions.
+    const uint32_t T = wta_threshold(key >> 16, uq);
     const uint32_t Tc = min(T, 0x8000u), TT = Tc | (Tc << 16);
     us2 hits = {0, 0};
 #pragma unroll
@@ -417,7 +427,18 @@ __device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK
     }
     uint32_t nb = (__builtin_amdgcn_ubfe(vm, hsel, 16) << 16) | __builtin_amdgcn_ubfe(vp, hsel, 16);
     nb = row16_or_u32(nb);
-    const int sm = (int)(nb >> 16), sp = (int)(nb & 0xFFFFu);
+    // best < 256 and the count only matters up to 4 (at most three positions are exempt): both fit the low half
+    return WtaPart{key | (min(cnt, 255u) << 8), nb};
+}
+
+// The per-pixel arithmetic on the reduced words (lane-local: k_sweep runs it once per 16 pixels,
+// each lane finishing a different pixel).  D = number of disparities.
+template <int D>
+__device__ __forceinline__ uint2 wta_finish(WtaPart w, UniqK uq) {
+    const int minS = (int)(w.key >> 16), best = (int)(w.key & 0xFFu);
+    const uint32_t cnt = (w.key >> 8) & 0xFFu;
+    const uint32_t T = wta_threshold((uint32_t)minS, uq);
+    const int sm = (int)(w.nb >> 16), sp = (int)(w.nb & 0xFFFFu);
     const bool inner = 0 < best && best < D - 1;
     const uint32_t exempt = (uint32_t)((uint32_t)minS < T) + (uint32_t)(best > 0 && (uint32_t)sm < T) +
                             (uint32_t)(best < D - 1 && (uint32_t)sp < T);
@@ -434,6 +455,11 @@ __device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK
     const bool ok = minS < 32767 && !bad;  // minS == 32767: every S saturated, no minimum
     const int dv = ok ? best * 16 + sub : -16, rw = ok ? best : -1;
     return make_uint2(((uint32_t)dv & 0xFFFFu) | ((uint32_t)rw << 16), (uint32_t)minS);
+}
+
+template <int N>
+__device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK uq) {
+    return wta_finish<32 * N>(wta_reduce<N>(s, q, uq), uq);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -63,12 +63,16 @@ __host__ __device__ constexpr size_t sweep_lds_bytes() {
 // neighbour (0 resp. 15 of the row) keeps what the register held before: "no such disparity" =
 // 0x7FFF7FFF, set once before the loop and never overwritten there, so the same register is shifted
 // into every step without being re-initialised (two moves per path and step saved).
-template <int N>
+// KEEP = false (sweep 2, which has no registers to spare) re-initialises them every step instead.
+template <int N, bool KEEP>
 __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&r)[N], uint32_t dd, uint32_t P1P1,
                                            uint32_t P2P2, uint32_t (&L)[N], uint32_t& dd_out, uint32_t (&edge)[2]) {
-    edge[0] = dpp<DPP_ROW_SHR1>(edge[0], r[N - 1]);
-    edge[1] = dpp<DPP_ROW_SHL1>(edge[1], r[0]);
-    const uint32_t prevHi = edge[0], nextLo = edge[1];
+    if (KEEP) {
+        edge[0] = dpp<DPP_ROW_SHR1>(edge[0], r[N - 1]);
+        edge[1] = dpp<DPP_ROW_SHL1>(edge[1], r[0]);
+    }
+    const uint32_t prevHi = KEEP ? edge[0] : dpp<DPP_ROW_SHR1>(0x7FFF7FFFu, r[N - 1]);
+    const uint32_t nextLo = KEEP ? edge[1] : dpp<DPP_ROW_SHL1>(0x7FFF7FFFu, r[0]);
     uint32_t m[N + 1];
     m[0] = __builtin_amdgcn_alignbit(r[0], prevHi, 16);
 #pragma unroll
@@ -155,6 +159,8 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
     for (int k = 0; k < N; k++) r0[k] = dn[k] = dr[0][k] = dr[1][k] = 0;
     const UniqK uqk = make_uniq(a.uniq);
+    WtaPart stash = {0u, 0u};              // sweep 2: reduced WTA words of the pixel this lane will finish
+    uint32_t stash_rq = 0xFFFFFFFFu;       // ... and its record index (all ones: nothing kept)
     uint32_t edge[4][2];  // per path: DPP landing registers of sweep_path
 #pragma unroll
     for (int k = 0; k < 4; k++) edge[k][0] = edge[k][1] = 0x7FFF7FFFu;
@@ -224,10 +230,10 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     dd_dl = st_r ? P2P2 : dd_dl;
                 }
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
-                sweep_path<N>(cb[j], r0, dd0, P1P1, P2P2, L0, n0, edge[0]);                  // horizontal
-                sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, P2P2, L1, n1, edge[1]);   // from (x-1, y-1): read two steps ago
-                sweep_path<N>(cb[j], dn, dn_dd, P1P1, P2P2, L2, n2, edge[2]);               // from (x,   y-1): read last step
-                sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, P2P2, L3, n3, edge[3]);            // from (x+1, y-1): read now
+                sweep_path<N, !SECOND>(cb[j], r0, dd0, P1P1, P2P2, L0, n0, edge[0]);                  // horizontal
+                sweep_path<N, !SECOND>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, P2P2, L1, n1, edge[1]);   // from (x-1, y-1): read two steps ago
+                sweep_path<N, !SECOND>(cb[j], dn, dn_dd, P1P1, P2P2, L2, n2, edge[2]);               // from (x,   y-1): read last step
+                sweep_path<N, !SECOND>(cb[j], in_dl, dd_dl, P1P1, P2P2, L3, n3, edge[3]);            // from (x+1, y-1): read now
                 // the parts of this step's record that are used later go straight into their registers
                 load_regs<N>(src + PXW + q * N, dn);
                 load_regs<N>(src + 2 * PXW + q * N, dr[j & 1]);
@@ -253,8 +259,19 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 }
                 dd0 = n0;
                 if (SECOND) {
-                    const uint2 w = wta_record<N>(snew, q, uqk);  // all 16 lanes hold the same record
-                    if (active) recg[recq[j]] = w;
+                    // The reductions leave the same three words in all 16 lanes of the row's group;
+                    // lane (step mod 16) keeps them, and once per 16 steps every lane finishes the
+                    // pixel it kept (thresholds, sub-pixel division, record) and stores its record:
+                    // the lane-local arithmetic runs once per 16 pixels instead of 16-fold redundantly.
+                    const WtaPart w = wta_reduce<N>(snew, q, uqk);
+                    const bool mine = q == ((tau + j) & 15);
+                    stash.key = mine ? w.key : stash.key;
+                    stash.nb = mine ? w.nb : stash.nb;
+                    stash_rq = mine ? (active ? recq[j] : 0xFFFFFFFFu) : stash_rq;
+                    if (j == SW_DEPTH - 1 && ((tau + j) & 15) == 15) {
+                        if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk);
+                        stash_rq = 0xFFFFFFFFu;
+                    }
                 } else {
                     if (active) store_regs<N>(Sg + offq[j], snew);
                 }
@@ -267,6 +284,8 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 SW_PROF(pacc[0] += T1 - T0; pacc[1] += T2 - T1; pacc[2] += T3 - T2; pacc[3] += T4 - T3;)
             }
         }
+        // pixels kept since the last 16-step boundary
+        if (SECOND && stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk);
         SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
     } else {
         bool aborted = false;
