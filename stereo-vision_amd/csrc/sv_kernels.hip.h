@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
         uint32_t pv[N];
 #pragma unroll
         for (int k = 0; k < N; k++) pv[k] = 0;
-#pragma unroll
+#pragma unroll 1  // one plane's operands in registers at a time (cn = 1: no loop at all)
         for (int ch = 0; ch < cn; ch++) {
             const uint32_t ug = (lrec.x & 0xFFu) * 0x10001u, ug0 = ((lrec.x >> 8) & 0xFFu) * 0x10001u;
             const uint32_t ug1 = ((lrec.x >> 16) & 0xFFu) * 0x10001u, ur = (lrec.x >> 24) * 0x10001u;
