@@ -164,20 +164,29 @@ __host__ __device__ inline int cost_plane_pitch(int W) { return (W + 2 + 7) & ~7
 // cn = 1: gray images [frame][H][W].  cn = 3: interleaved RGB [frame][H][W][3]; every colour plane
 // gets its own statistics (blockIdx.z = ((frame * cn + channel) * 2 + is_right)), which is what
 // cv::StereoSGBM's calcPixelCostBT does with 8UC3 input (matchSGBM, StereoMatcher.cpp:392-417).
+// A block covers STATS_TX = 254 pixels of a row plus one halo pixel on each side: every thread
+// computes the clipped gradient and raw value of its own pixel (7 byte loads) and takes its
+// neighbours' from LDS, instead of recomputing them (21 loads).
+constexpr int STATS_TX = 254;
 __global__ __launch_bounds__(256) void k_stats_planes(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                        uint2* __restrict__ stat_l, uint16_t* __restrict__ rp, int W, int H, int WP,
                                                        int cap, int cn) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint16_t gr_lds[256];
+    const int x = blockIdx.x * STATS_TX + (int)threadIdx.x - 1;  // halo pixel on each side of the block's span
     const int y = blockIdx.y;
-    if (x >= W) return;
     const int fc = blockIdx.z >> 1, frame = fc / cn, ch = fc - frame * cn;
     const bool is_right = blockIdx.z & 1;
     const uint8_t* img = (is_right ? right : left) + (size_t)frame * W * H * cn + ch;
-    int g = grad_at(img, W, H, x, y, cap, cn), r = raw_at(img, W, x, y, cap, cn);
-    int gl = x > 0 ? (g + grad_at(img, W, H, x - 1, y, cap, cn)) / 2 : g;
-    int gr = x < W - 1 ? (g + grad_at(img, W, H, x + 1, y, cap, cn)) / 2 : g;
-    int rl = x > 0 ? (r + raw_at(img, W, x - 1, y, cap, cn)) / 2 : r;
-    int rr = x < W - 1 ? (r + raw_at(img, W, x + 1, y, cap, cn)) / 2 : r;
+    const bool inside = x >= 0 && x < W;
+    const int g = inside ? grad_at(img, W, H, x, y, cap, cn) : 0, r = inside ? raw_at(img, W, x, y, cap, cn) : 0;
+    gr_lds[threadIdx.x] = (uint16_t)(g | (r << 8));
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x > STATS_TX || x >= W) return;
+    const int lo = gr_lds[threadIdx.x - 1], hi = gr_lds[threadIdx.x + 1];
+    int gl = x > 0 ? (g + (lo & 0xFF)) / 2 : g;
+    int gr = x < W - 1 ? (g + (hi & 0xFF)) / 2 : g;
+    int rl = x > 0 ? (r + (lo >> 8)) / 2 : r;
+    int rr = x < W - 1 ? (r + (hi >> 8)) / 2 : r;
     int g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
     int r0 = min(min(rl, rr), r), r1 = max(max(rl, rr), r);
     if (!is_right) {
