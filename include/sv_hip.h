@@ -271,13 +271,28 @@ int sv_filter_wls_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stri
  * reads the map's min/max back to size the grid (one stream synchronisation).
  * Grids above 2^27 cells (sigmas near 1 on a large map) are rejected with
  * SV_ERR_UNSUPPORTED.  BLF_DISABLED needs no call (the reference clones);
- * BLF_CUDA (cv::cuda::DisparityBilateralFilter, OpenCV-CUDA only) is not
- * provided.                                                                   */
+ * BLF_CUDA: sv_filter_blf_joint_* below.                                      */
 int sv_filter_blf_dev(sv_ctx* ctx, const int16_t* disp16_dev, double sigma_color, double sigma_space,
                       int16_t* disp16_blf_dev, uint8_t* vis_blf_dev);
 int sv_filter_blf_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride, double sigma_color,
                        double sigma_space, int16_t* disp16_blf_host, size_t out16_stride,
                        uint8_t* vis_blf_host, size_t out8_stride);
+
+/* Replaces the BLF_CUDA branch of StereoMatcherNew::filterBLF (StereoMatcher.cpp:101-116; filter made
+ * at :292-301): cv::cuda::DisparityBilateralFilter(ndisp = numberOfDisparities, radius 7, iters 2) with
+ * sigma_range = sigmaColorBLF on the CV_16S map, guided by the gray rectified left image, followed by
+ * getDisparityVis(.,.,3) when vis_blf != NULL.  EXT item (OpenCV-CUDA is not in the tree): restated
+ * from the published algorithm, edge_threshold 0.1 and max_disc_threshold 0.2 as in OpenCV.  OpenCV's
+ * kernel updates the map in place while neighbouring threads read it (result depends on timing);
+ * here every half-pass reads the map as it was before the half-pass (deterministic).
+ * _dev: guide_gray_dev = 8-bit gray [H][W].  _host: guide_rgb_host = 8UC3 rectified left image (the
+ * cvtColor of :103-104 runs on the device), NULL = the one kept by the last sv_compute_rgb_host.
+ * disp16_blf may be the input buffer (_dev).                                                        */
+int sv_filter_blf_joint_dev(sv_ctx* ctx, const int16_t* disp16_dev, const uint8_t* guide_gray_dev, int ndisp, int radius,
+                            int iters, double sigma_range, int16_t* disp16_blf_dev, uint8_t* vis_blf_dev);
+int sv_filter_blf_joint_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_stride, const uint8_t* guide_rgb_host,
+                             size_t guide_stride, int ndisp, int radius, int iters, double sigma_range,
+                             int16_t* disp16_blf_host, size_t out16_stride, uint8_t* vis_blf_host, size_t out8_stride);
 
 /* Replaces DispModule::depthFromDisparity (DispModule.cpp:320-366), with the
  * non-aliased read.  mapper = MapperL (CV_32FC2,

@@ -151,6 +151,77 @@ void svref_world_image(const int16_t* disp16, int W, int H, const float* mapper,
         }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * A16 filterBLF, BLF_CUDA branch (StereoMatcher.cpp:101-116, set up at :292-301): EXT item,
+ * cv::cuda::DisparityBilateralFilter(ndisp = numberOfDisparities, radius 7, iters 2) with
+ * sigma_range = sigmaColorBLF, edge_threshold 0.1, max_disc_threshold 0.2 (its defaults), applied
+ * to the CV_16S disparity16 map with the gray rectified left image as the guide.  Restated from
+ * the published algorithm (OpenCV cudastereo, disp_bilateral_filter; OpenCV is not installed:
+ * parity unpinned):
+ *   table_color[i] = (float)exp(-(double)(i*i) / (2 sigma^2)),      i = |guide difference|
+ *   table_space[dy][dx] = expf(-sqrtf(dy*dy + dx*dx) / (radius + 1))
+ *   edge_disc = max(1, (short)(ndisp*0.1 + 0.5)),  max_disc = (short)(ndisp*0.2 + 0.5)
+ *   iters x { half-pass t = 0, half-pass t = 1 }; a half-pass visits the interior pixels with
+ *   (x + y + t) even... precisely x = 2k + ((y + t) & 1); a pixel whose 4-neighbourhood differs from
+ *   it by >= edge_disc takes, among {itself, up, left, down, right}, the value with the smallest
+ *   cost = sum over the (2r+1)^2 window (clipped to the image, rows then columns ascending) of
+ *          min(max_disc, |disp(window) - candidate|) * table_color * table_space   (float adds);
+ *   ties go to the first candidate in that order.
+ * OpenCV's kernel updates the map in place while other threads still read it, so its result depends
+ * on thread timing; this restatement fixes the schedule "every pixel of a half-pass reads the map as
+ * it was before the half-pass".  OpenCV's colour table has 255 entries and is indexed with up to
+ * 255; here it has 256.
+ * ------------------------------------------------------------------------------------------- */
+int svref_blf_joint(const int16_t* disp, const uint8_t* guide, int W, int H, int ndisp, int radius, int iters, double sigma_range,
+                    int16_t* out) {
+    if (W < 1 || H < 1 || ndisp < 1 || radius < 1 || radius > 32 || iters < 1 || !(sigma_range > 0.0)) return -1;
+    float tc[256], ts[33][33];
+    for (int i = 0; i < 256; i++) tc[i] = (float)exp(-(double)(i * i) / (2 * sigma_range * sigma_range));
+    const float dist_space = (float)radius + 1.0f;
+    for (int y = 0; y <= radius; y++)
+        for (int x = 0; x <= radius; x++) ts[y][x] = expf(-sqrtf((float)(y * y) + (float)(x * x)) / dist_space);
+    short edge_disc = (short)(ndisp * 0.1f + 0.5);
+    if (edge_disc < 1) edge_disc = 1;
+    const short max_disc = (short)(ndisp * 0.2f + 0.5);
+    const size_t n = (size_t)W * H;
+    int16_t* cur = (int16_t*)malloc(n * sizeof(int16_t));
+    if (!cur) return -1;
+    memcpy(out, disp, n * sizeof(int16_t));
+    for (int it = 0; it < iters; it++)
+        for (int t = 0; t < 2; t++) {
+            memcpy(cur, out, n * sizeof(int16_t)); /* the map as it was before this half-pass */
+            for (int y = 1; y < H - 1; y++)
+                for (int x = 1 + ((y + t + 1) & 1); x < W - 1; x += 2) { /* x = 2k + ((y + t) & 1), x >= 1 */
+                    int dp[5];
+                    dp[0] = cur[(size_t)y * W + x];
+                    dp[1] = cur[(size_t)(y - 1) * W + x];
+                    dp[2] = cur[(size_t)y * W + x - 1];
+                    dp[3] = cur[(size_t)(y + 1) * W + x];
+                    dp[4] = cur[(size_t)y * W + x + 1];
+                    if (!(abs(dp[1] - dp[0]) >= edge_disc || abs(dp[2] - dp[0]) >= edge_disc || abs(dp[3] - dp[0]) >= edge_disc ||
+                          abs(dp[4] - dp[0]) >= edge_disc))
+                        continue;
+                    const int ymin = imax(0, y - radius), xmin = imax(0, x - radius);
+                    const int ymax = imin(H - 1, y + radius), xmax = imin(W - 1, x + radius);
+                    float cost[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    const int ic = guide[(size_t)y * W + x];
+                    for (int yi = ymin; yi <= ymax; yi++)
+                        for (int xi = xmin; xi <= xmax; xi++) {
+                            const float weight = tc[abs((int)guide[(size_t)yi * W + xi] - ic)] * ts[abs(y - yi)][abs(x - xi)];
+                            const int dr = cur[(size_t)yi * W + xi];
+                            for (int k = 0; k < 5; k++) cost[k] += (float)imin(max_disc, abs(dr - dp[k])) * weight;
+                        }
+                    float minimum = 3.402823466e+38f;
+                    int id = 0;
+                    for (int k = 0; k < 5; k++)
+                        if (cost[k] < minimum) { minimum = cost[k]; id = k; }
+                    out[(size_t)y * W + x] = (int16_t)dp[id];
+                }
+        }
+    free(cur);
+    return 0;
+}
+
 const char* svref_version(void) { return "sv_ref 1 (restated SGBM, parity unpinned)"; }
 
 /* Limits under which every int16 store of the reference is wrap-free, so the

@@ -126,6 +126,10 @@ int svref_blf(const int16_t* src, int W, int H, double sigma_color, double sigma
 void svref_world_image(const int16_t* disp16, int W, int H, const float* mapper, const double* Q, const double* RLrect,
                        const double* HL_root, float* cart, float* cyl);
 
+/* A16 filterBLF / BLF_CUDA (EXT): cv::cuda::DisparityBilateralFilter with a gray guide, deterministic schedule */
+int svref_blf_joint(const int16_t* disp, const uint8_t* guide, int W, int H, int ndisp, int radius, int iters, double sigma_range,
+                    int16_t* out);
+
 const char* svref_version(void);
 #ifdef __cplusplus
 }

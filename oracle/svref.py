@@ -102,6 +102,8 @@ def lib():
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.svref_world_image.restype = None
         L.svref_world_image.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
+        L.svref_blf_joint.restype = C.c_int
+        L.svref_blf_joint.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
         L.svref_blf.restype = C.c_int
         L.svref_blf.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.svref_init_rectify_map.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -321,3 +323,14 @@ def world_image(disp16, mapper, Q, RLrect, HL_root):
     cyl = np.empty((H, W, 3), np.float32)
     lib().svref_world_image(_ptr(d), W, H, _ptr(mp), _ptr(Qm), _ptr(Rm), _ptr(Hm), _ptr(cart), _ptr(cyl))
     return cart, cyl
+
+
+def blf_joint(disp16, guide_gray, ndisp, sigma_range=10.0, radius=7, iters=2):
+    """filterBLF / BLF_CUDA: cv::cuda::DisparityBilateralFilter(ndisp, 7, 2) with a gray guide (EXT restatement)."""
+    src = np.ascontiguousarray(disp16, dtype=np.int16)
+    g = np.ascontiguousarray(guide_gray, dtype=np.uint8)
+    assert g.shape == src.shape
+    dst = np.empty_like(src)
+    if lib().svref_blf_joint(_ptr(src), _ptr(g), src.shape[1], src.shape[0], ndisp, radius, iters, float(sigma_range), _ptr(dst)) != 0:
+        raise ValueError("svref_blf_joint: bad arguments")
+    return dst

@@ -91,4 +91,46 @@ __global__ __launch_bounds__(256) void k_blf_slice(const int16_t* d, int W, int 
     out[(size_t)y * W + x] = (int16_t)(q < -32768.0 ? -32768.0 : (q > 32767.0 ? 32767.0 : q));
 }
 
+// ---------------------------------------------------------------------------------------------
+// filterBLF, BLF_CUDA branch (StereoMatcher.cpp:101-116): the joint bilateral disparity refinement
+// of cv::cuda::DisparityBilateralFilter (EXT item; algorithm and the fixed read-before-write
+// schedule: include/sv_hip.h, sv_filter_blf_joint_*).  One half-pass: thread = one pixel of the pass's
+// checkerboard colour; `cur` is the map before the half-pass, `out` starts as a copy of it.
+// tc[256] / ts[(radius+1)^2]: colour and space weight tables made on the host.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blf_joint(const int16_t* __restrict__ cur, int16_t* __restrict__ out,
+                                                    const uint8_t* __restrict__ guide, const float* __restrict__ tc,
+                                                    const float* __restrict__ ts, int W, int H, int t, int radius, int edge_disc,
+                                                    int max_disc) {
+    const int y = blockIdx.y;
+    const int x = ((blockIdx.x * blockDim.x + threadIdx.x) << 1) + ((y + t) & 1);
+    if (!(y > 0 && y < H - 1 && x > 0 && x < W - 1)) return;
+    int dp[5];
+    dp[0] = cur[(size_t)y * W + x];
+    dp[1] = cur[(size_t)(y - 1) * W + x];
+    dp[2] = cur[(size_t)y * W + x - 1];
+    dp[3] = cur[(size_t)(y + 1) * W + x];
+    dp[4] = cur[(size_t)y * W + x + 1];
+    if (!(abs(dp[1] - dp[0]) >= edge_disc || abs(dp[2] - dp[0]) >= edge_disc || abs(dp[3] - dp[0]) >= edge_disc ||
+          abs(dp[4] - dp[0]) >= edge_disc))
+        return;
+    const int ymin = max(0, y - radius), xmin = max(0, x - radius);
+    const int ymax = min(H - 1, y + radius), xmax = min(W - 1, x + radius);
+    float cost[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const int ic = guide[(size_t)y * W + x];
+    for (int yi = ymin; yi <= ymax; yi++)
+        for (int xi = xmin; xi <= xmax; xi++) {
+            const float weight = tc[abs((int)guide[(size_t)yi * W + xi] - ic)] * ts[abs(y - yi) * (radius + 1) + abs(x - xi)];
+            const int dr = cur[(size_t)yi * W + xi];
+#pragma unroll
+            for (int k = 0; k < 5; k++) cost[k] += (float)min(max_disc, abs(dr - dp[k])) * weight;
+        }
+    float minimum = 3.402823466e+38f;
+    int best = dp[0];
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        if (cost[k] < minimum) { minimum = cost[k]; best = dp[k]; }
+    out[(size_t)y * W + x] = (int16_t)best;
+}
+
 }  // namespace svk

@@ -84,7 +84,9 @@ struct sv_ctx {
     Buf wls_lut, wls_wh, wls_wv, wls_cur, wls_tmp;  // WLS: weight table, edge weights, work images (float)
     Buf wls_g, wls_v, wls_o16, wls_o8;              // WLS host entry point staging
     Buf world_cart, world_cyl;                      // f32 [H][W][3] staging of sv_world_image_host
-    Buf blf_a, blf_b, blf_mm, blf_o16, blf_o8;      // BLF: the two grids, min/max words, host entry point staging
+    Buf blf_a, blf_b, blf_mm, blf_o16, blf_o8, blf_tab, blf_tmp, blf_gray;      // BLF: the two grids, min/max words, host entry point staging
+    double blf_tab_sigma = -1.0;                    // colour / space tables on the device were built for these
+    int blf_tab_radius = -1;
     float wls_lut_sigma = -1.0f;                    // sigma the device table was built for
     bool have_maps = false;  // both cameras
     bool have_map[2] = {false, false};
@@ -728,7 +730,7 @@ int sv_destroy(sv_ctx* c) {
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->mapper_lr[0], &c->mapper_lr[1], &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt, &c->wls_lut, &c->wls_wh, &c->wls_wv, &c->wls_cur, &c->wls_tmp, &c->wls_g,
-                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->world_cart, &c->world_cyl, &c->blf_a, &c->blf_b, &c->blf_mm, &c->blf_o16, &c->blf_o8, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
+                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->world_cart, &c->world_cyl, &c->blf_a, &c->blf_b, &c->blf_mm, &c->blf_o16, &c->blf_o8, &c->blf_tab, &c->blf_tmp, &c->blf_gray, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
             for (Buf* b : all) release(*b);
             if (c->sw_error) (void)hipHostFree(c->sw_error);
             if (c->slots_ok)
@@ -1327,6 +1329,98 @@ int sv_filter_blf_host(sv_ctx* c, const int16_t* d16, size_t ds, double sigma_co
     if (out8 && (rc = ensure(c, c->blf_o8, W * H))) return rc;
     HIPCHK(c, copy2d(c->d16tmp.p, 2 * W, d16, ds, 2 * W, H, hipMemcpyHostToDevice, c->stream));
     if ((rc = blf_dev(c, (const int16_t*)c->d16tmp.p, sigma_color, sigma_space, (int16_t*)c->blf_o16.p, out8 ? (uint8_t*)c->blf_o8.p : nullptr)))
+        return rc;
+    HIPCHK(c, copy2d(out16, os16, c->blf_o16.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    if (out8) HIPCHK(c, copy2d(out8, os8, c->blf_o8.p, W, W, H, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SV_OK;
+}
+
+// filterBLF / BLF_CUDA semantics on the device (kernel: sv_blf.hip.h, k_blf_joint).  guide: gray u8.
+static int blf_joint_dev(sv_ctx* c, const int16_t* d16, const uint8_t* guide, int ndisp, int radius, int iters, double sigma_range,
+                         int16_t* out16, uint8_t* out8) {
+    const int W = c->W, H = c->H;
+    const size_t n = (size_t)W * H;
+    int rc;
+    const size_t tab_floats = 256 + (size_t)(radius + 1) * (radius + 1);
+    if ((rc = ensure(c, c->blf_tab, (256 + 33 * 33) * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->blf_tmp, n * 2))) return rc;
+    if (c->blf_tab_sigma != sigma_range || c->blf_tab_radius != radius) {
+        // calc_color_weighted_table / calc_space_weighted_filter of OpenCV's filter, on the host
+        std::vector<float> tab(tab_floats);
+        for (int i = 0; i < 256; i++) tab[i] = (float)std::exp(-(double)(i * i) / (2 * sigma_range * sigma_range));
+        const float dist_space = (float)radius + 1.0f;
+        for (int y = 0; y <= radius; y++)
+            for (int x = 0; x <= radius; x++)
+                tab[256 + (size_t)y * (radius + 1) + x] = expf(-sqrtf((float)(y * y) + (float)(x * x)) / dist_space);
+        HIPCHK(c, hipMemcpyAsync(c->blf_tab.p, tab.data(), tab_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // tab goes out of scope
+        c->blf_tab_sigma = sigma_range;
+        c->blf_tab_radius = radius;
+    }
+    short edge_disc = (short)(ndisp * 0.1f + 0.5);
+    if (edge_disc < 1) edge_disc = 1;
+    const short max_disc = (short)(ndisp * 0.2f + 0.5);
+    const float* tc = (const float*)c->blf_tab.p;
+    if (out16 != d16) HIPCHK(c, hipMemcpyAsync(out16, d16, n * 2, hipMemcpyDeviceToDevice, c->stream));
+    const dim3 grid((unsigned)((W / 2 + 1 + 255) / 256), (unsigned)H);
+    for (int it = 0; it < iters; it++)
+        for (int t = 0; t < 2; t++) {
+            HIPCHK(c, hipMemcpyAsync(c->blf_tmp.p, out16, n * 2, hipMemcpyDeviceToDevice, c->stream));  // the map before this half-pass
+            hipLaunchKernelGGL(svk::k_blf_joint, grid, dim3(256), 0, c->stream, (const int16_t*)c->blf_tmp.p, out16, guide, tc, tc + 256,
+                               W, H, t, radius, (int)edge_disc, (int)max_disc);
+            HIPCHK(c, hipGetLastError());
+        }
+    if (out8) {  // getDisparityVis(disparity16_blf, disparity_blf, 3), StereoMatcher.cpp:113
+        hipLaunchKernelGGL(svk::k_vis, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, out16, out8, n, 3);
+        HIPCHK(c, hipGetLastError());
+    }
+    return SV_OK;
+}
+
+static int blf_joint_args(sv_ctx* c, const void* d16, const void* out16, int ndisp, int radius, int iters, double sigma_range) {
+    if (!d16 || !out16) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (ndisp < 1 || radius < 1 || radius > 32 || iters < 1 || iters > 64 || !(sigma_range > 0.0))
+        return fail(c, SV_ERR_INVALID_ARG, "need ndisp >= 1, radius in [1,32], iters in [1,64], sigma_range > 0");
+    return SV_OK;
+}
+
+int sv_filter_blf_joint_dev(sv_ctx* c, const int16_t* d16, const uint8_t* guide_gray, int ndisp, int radius, int iters,
+                            double sigma_range, int16_t* out16, uint8_t* out8) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    int rc = blf_joint_args(c, d16, out16, ndisp, radius, iters, sigma_range);
+    if (rc) return rc;
+    if (!guide_gray) return fail(c, SV_ERR_INVALID_ARG, "NULL guide image");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    return blf_joint_dev(c, d16, guide_gray, ndisp, radius, iters, sigma_range, out16, out8);
+}
+
+int sv_filter_blf_joint_host(sv_ctx* c, const int16_t* d16, size_t ds, const uint8_t* guide_rgb, size_t gs, int ndisp, int radius,
+                             int iters, double sigma_range, int16_t* out16, size_t os16, uint8_t* out8, size_t os8) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    int rc = blf_joint_args(c, d16, out16, ndisp, radius, iters, sigma_range);
+    if (rc) return rc;
+    const size_t W = c->W, H = c->H;
+    if (ds < 2 * W || os16 < 2 * W || (out8 && os8 < W) || (guide_rgb && gs < 3 * W)) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    if (!guide_rgb && !c->rect_l.p) return fail(c, SV_ERR_INVALID_ARG, "no guide image: pass one or call sv_compute_rgb_host first");
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    if ((rc = ensure(c, c->d16tmp, W * H * 2))) return rc;
+    if ((rc = ensure(c, c->blf_o16, W * H * 2))) return rc;
+    if ((rc = ensure(c, c->blf_gray, W * H))) return rc;
+    if (out8 && (rc = ensure(c, c->blf_o8, W * H))) return rc;
+    HIPCHK(c, copy2d(c->d16tmp.p, 2 * W, d16, ds, 2 * W, H, hipMemcpyHostToDevice, c->stream));
+    const uint8_t* rgb_dev = (const uint8_t*)c->rect_l.p;  // the rectified left image of the last sv_compute_rgb_host
+    if (guide_rgb) {
+        if ((rc = ensure(c, c->wls_g, W * H * 3))) return rc;
+        HIPCHK(c, copy2d(c->wls_g.p, 3 * W, guide_rgb, gs, 3 * W, H, hipMemcpyHostToDevice, c->stream));
+        rgb_dev = (const uint8_t*)c->wls_g.p;
+    }
+    // cv::cvtColor(grayL, grayL, CV_BGR2GRAY) on the RGB-ordered rectified left image (StereoMatcher.cpp:103-104)
+    if ((rc = sv_gray_from_rgb_dev(c, rgb_dev, (uint8_t*)c->blf_gray.p))) return rc;
+    if ((rc = blf_joint_dev(c, (const int16_t*)c->d16tmp.p, (const uint8_t*)c->blf_gray.p, ndisp, radius, iters, sigma_range,
+                            (int16_t*)c->blf_o16.p, out8 ? (uint8_t*)c->blf_o8.p : nullptr)))
         return rc;
     HIPCHK(c, copy2d(out16, os16, c->blf_o16.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
     if (out8) HIPCHK(c, copy2d(out8, os8, c->blf_o8.p, W, W, H, hipMemcpyDeviceToHost, c->stream));

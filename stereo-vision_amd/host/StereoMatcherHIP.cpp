@@ -131,10 +131,22 @@ void StereoMatcherNew::filterBLF(std::string kind) {
             disparity16_blf = out16;
             return;
         }
-        case BLF_CUDA:
-            // StereoMatcher.cpp:101-116 is cv::cuda::DisparityBilateralFilter (OpenCV-CUDA only)
-            std::cout << "[StereoMatcherNew] !! BLF_CUDA needs OpenCV-CUDA and is not part of the sgbm_hip build, passing through." << std::endl;
-            break;
+        case BLF_CUDA: {
+            // StereoMatcher.cpp:101-116: cv::cuda::DisparityBilateralFilter(numberOfDisparities, 7, 2), sigma_range =
+            // sigmaColorBLF (:292-301), guided by the gray rectified left image that compute() left on the device
+            if (!ctx || input16.empty()) break;
+            Image out16(input16.rows, input16.cols, 1, 2), out8(input16.rows, input16.cols, 1, 1);
+            last_rc = sv_filter_blf_joint_host(ctx, input16.ptr<int16_t>(), input16.step(), nullptr, 0,
+                                               stereo_parameters.numberOfDisparities, 7, 2, stereo_parameters.sigmaColorBLF,
+                                               out16.ptr<int16_t>(), out16.step(), out8.ptr<uint8_t>(), out8.step());
+            if (last_rc != 0) {
+                std::cout << "[StereoMatcherNew] !! sv_filter_blf_joint_host failed: " << sv_last_error(ctx) << std::endl;
+                break;
+            }
+            disparity_blf = out8;
+            disparity16_blf = out16;
+            return;
+        }
         case BLF_DISABLED:
         default:
             break;

@@ -2,7 +2,7 @@
 // DispModule::updateModule() (/root/reference/modules/DisparityModule/DispModule.cpp:661-814) on
 // synthetic RGB pairs, without YARP: setImages -> matcher->compute() -> filterBLF("base") ->
 // filterWLS("blf") -> getDisparity("wls") -> getDisparity16("wls") -> depthFromDisparity.
-// Usage: sv_module_sim [width height numDisp frames paths wls(0|1) blf(0|1)]
+// Usage: sv_module_sim [width height numDisp frames paths wls(0|1) blf(0|1|2)]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,13 +41,13 @@ int main(int argc, char** argv) {
     int W = argc > 1 ? atoi(argv[1]) : 640, H = argc > 2 ? atoi(argv[2]) : 480, D = argc > 3 ? atoi(argv[3]) : 128;
     int frames = argc > 4 ? atoi(argv[4]) : 20, paths = argc > 5 ? atoi(argv[5]) : 8;
     const bool wls = argc > 6 && atoi(argv[6]) != 0;  // --wls (DispModule.cpp:259-265)
-    const bool blf = argc > 7 && atoi(argv[7]) != 0;  // --blf (DispModule.cpp:253-258): BLF_ORIGINAL
+    const int blf = argc > 7 ? atoi(argv[7]) : 0;     // 1 = --blf BLF_ORIGINAL, 2 = --cuda_blf BLF_CUDA (DispModule.cpp:253-258)
     StereoCamera cam;
     StereoMatcherNew matcher(&cam);
     matcher.paths = paths;
     matcher.setAlgorithm("sgbm_hip");  // DispModule.cpp:246-251 keyword
     // DispModule::initializeStereoParams defaults (DispModule.cpp:369-394), numDisp from the CLI
-    matcher.setParameters(0, D, 7, 0, 63, 15, 50, 16, 10.0, 10.0, 4500., 1.0, blf ? BLF_ORIGINAL : BLF_DISABLED, wls ? WLS_ENABLED : WLS_DISABLED, SGBM_HIP);
+    matcher.setParameters(0, D, 7, 0, 63, 15, 50, 16, 10.0, 10.0, 4500., 1.0, blf == 1 ? BLF_ORIGINAL : (blf == 2 ? BLF_CUDA : BLF_DISABLED), wls ? WLS_ENABLED : WLS_DISABLED, SGBM_HIP);
     matcher.updateHIPParams();
     // identity mapper + a plausible Q so the depth stage runs
     Image mapper(H, W, 2, 4);

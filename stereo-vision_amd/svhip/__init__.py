@@ -30,7 +30,7 @@ EXPORTS = (
     "sv_compute_gray_host", "sv_submit_gray_host", "sv_wait_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
-    "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_compute_rgb_batch_dev", "sv_disparity_vis_batch_dev", "sv_depth_batch_dev", "sv_world_image_dev", "sv_world_image_host",
+    "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_filter_blf_joint_dev", "sv_filter_blf_joint_host", "sv_compute_rgb_batch_dev", "sv_disparity_vis_batch_dev", "sv_depth_batch_dev", "sv_world_image_dev", "sv_world_image_host",
     "sv_synchronize", "sv_last_aggregation", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
     "sv_algorithmic_bytes", "sv_last_error", "sv_version")
@@ -109,6 +109,8 @@ def load():
     L.sv_compute_rgb_batch_dev.argtypes = [vp, i32, vp, vp, i32, vp, vp]
     L.sv_disparity_vis_batch_dev.argtypes = [vp, i32, vp, vp, i32]
     L.sv_depth_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.sv_filter_blf_joint_dev.argtypes = [vp, vp, vp, i32, i32, i32, C.c_double, vp, vp]
+    L.sv_filter_blf_joint_host.argtypes = [vp, vp, sz, vp, sz, i32, i32, i32, C.c_double, vp, sz, vp, sz]
     L.sv_filter_blf_dev.argtypes = [vp, vp, C.c_double, C.c_double, vp, vp]
     L.sv_filter_blf_host.argtypes = [vp, vp, sz, C.c_double, C.c_double, vp, sz, vp, sz]
     L.sv_init_rectify_map.argtypes = [vp, i32, vp, vp, i32, vp, vp]
@@ -337,6 +339,22 @@ class Matcher:
         self._chk(self._L.sv_filter_blf_host(self._h, _ptr(d), 2 * self.W, sigma_color, sigma_space, _ptr(out16), 2 * self.W,
                                              _ptr(out8) if vis else None, self.W))
         return (out16, out8) if vis else out16
+
+    def filter_blf_joint(self, disp16, ndisp, sigma_range=10.0, guide_rgb=None, radius=7, iters=2, vis=False):
+        """filterBLF / BLF_CUDA semantics on host arrays; guide_rgb None = rectified left image of the last compute_rgb."""
+        d = np.ascontiguousarray(disp16, np.int16)
+        g = np.ascontiguousarray(guide_rgb, np.uint8) if guide_rgb is not None else None
+        out16 = np.empty((self.H, self.W), np.int16)
+        out8 = np.empty((self.H, self.W), np.uint8) if vis else None
+        self._chk(self._L.sv_filter_blf_joint_host(self._h, _ptr(d), 2 * self.W, _ptr(g) if g is not None else None, 3 * self.W,
+                                                   ndisp, radius, iters, sigma_range, _ptr(out16), 2 * self.W,
+                                                   _ptr(out8) if vis else None, self.W))
+        return (out16, out8) if vis else out16
+
+    def filter_blf_joint_dev(self, disp_t, gray_t, out_t, ndisp, sigma_range=10.0, radius=7, iters=2, vis_out_t=None):
+        self._chk(self._L.sv_filter_blf_joint_dev(self._h, C.c_void_p(disp_t.data_ptr()), C.c_void_p(gray_t.data_ptr()), ndisp, radius,
+                                                  iters, sigma_range, C.c_void_p(out_t.data_ptr()),
+                                                  C.c_void_p(vis_out_t.data_ptr()) if vis_out_t is not None else None))
 
     def filter_blf_dev(self, disp_t, out_t, sigma_color=10.0, sigma_space=10.0, vis_out_t=None):
         self._chk(self._L.sv_filter_blf_dev(self._h, C.c_void_p(disp_t.data_ptr()), sigma_color, sigma_space,

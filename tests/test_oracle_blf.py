@@ -74,3 +74,52 @@ def test_blf_properties():
         svref.blf(d, 0.0, 10.0)
     with pytest.raises(ValueError):
         svref.blf(d, 10.0, -1.0)
+
+
+# ---- BLF_CUDA semantics (EXT): cv::cuda::DisparityBilateralFilter, deterministic schedule -------------
+
+def blf_joint_python(disp, guide, ndisp, sigma, radius=7, iters=2):
+    """Second restatement, scalar loops with float32 accumulation (small images only)."""
+    f32 = np.float32
+    H, W = disp.shape
+    tc = np.array([f32(np.exp(-float(i * i) / (2 * sigma * sigma))) for i in range(256)], f32)
+    ts = np.array([[np.exp(-np.sqrt(f32(y * y) + f32(x * x)) / f32(radius + 1.0)) for x in range(radius + 1)]
+                   for y in range(radius + 1)], f32)
+    edge = max(1, int(f32(ndisp) * f32(0.1) + 0.5))
+    maxd = int(f32(ndisp) * f32(0.2) + 0.5)
+    out = disp.astype(np.int64).copy()
+    g = guide.astype(np.int64)
+    for _ in range(iters):
+        for t in (0, 1):
+            cur = out.copy()
+            for y in range(1, H - 1):
+                for x in range(1, W - 1):
+                    if (x & 1) != ((y + t) & 1):
+                        continue
+                    dp = [cur[y, x], cur[y - 1, x], cur[y, x - 1], cur[y + 1, x], cur[y, x + 1]]
+                    if not any(abs(v - dp[0]) >= edge for v in dp[1:]):
+                        continue
+                    cost = [f32(0)] * 5
+                    for yi in range(max(0, y - radius), min(H - 1, y + radius) + 1):
+                        for xi in range(max(0, x - radius), min(W - 1, x + radius) + 1):
+                            w = f32(tc[abs(g[yi, xi] - g[y, x])] * ts[abs(y - yi), abs(x - xi)])
+                            for k in range(5):
+                                cost[k] = f32(cost[k] + f32(f32(min(maxd, abs(cur[yi, xi] - dp[k]))) * w))
+                    out[y, x] = dp[int(np.argmin(np.array(cost, f32)))]   # argmin: first minimum, as the < scan
+    return out.astype(np.int16)
+
+
+def test_blf_joint_two_restatements_agree():
+    W, H, D = 72, 40, 32
+    left, right, _ = synth.stereo_pair(12, W, H, D)
+    d = svref.sgbm(left, right, svref.default_params(D, 8))
+    got = svref.blf_joint(d, left, D, 10.0)
+    assert np.array_equal(got, blf_joint_python(d, left, D, 10.0))
+    assert 0.0 < (got != d).mean() < 0.5                     # only pixels at disparity edges move
+    assert np.array_equal(got[0], d[0]) and np.array_equal(got[:, 0], d[:, 0])   # border untouched
+    got1 = svref.blf_joint(d, left, D, 3.0, radius=3, iters=1)
+    assert np.array_equal(got1, blf_joint_python(d, left, D, 3.0, radius=3, iters=1))
+    flat = np.full((H, W), 160, np.int16)
+    assert np.array_equal(svref.blf_joint(flat, left, D), flat)   # no edge, nothing to do
+    with pytest.raises(ValueError):
+        svref.blf_joint(d, left, D, 0.0)
