@@ -126,7 +126,7 @@ def main():
     from svhip import synth
 
     W, H, D, paths = CONFIGS[args.config]
-    B = args.batch if args.config != "c4" else min(args.batch, 4)   # C4: 1.84 GB of volumes per pair
+    B = args.batch if args.config != "c4" else min(args.batch, 96)  # C4: 1.84 GB of volumes per pair (96 pairs = 177 GB)
     params = svhip.default_params(D, paths)  # SAD 7, P1 8*49, P2 32*49, cap 63, uniq 15, LR check on
     n_distinct = min(B, 8)
     seed0 = 202 if world == 1 else 500 + 16 * rank

@@ -61,7 +61,7 @@ struct sv_ctx {
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: 1.5 frames per workgroup pipeline
-    bool attr_sweep[2][4][2] = {}, attr_cost2[2][8] = {};
+    bool attr_sweep[2][8][2] = {}, attr_cost2[2][8] = {};
     int sweep_cw = 15;                 // compute waves per sweep workgroup (15: one workgroup per CU, 7: two)
     int n_cu = 256;
     // concurrent paths for small batches (run_paths_fanout)
@@ -371,9 +371,10 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     if (n_groups < 1) n_groups = 1;
     if (n_groups > nb) n_groups = nb;
     int fpg = (nb + n_groups - 1) / n_groups;
-    // a group's block of C / S must stay below 4 GiB (32-bit word offsets in the kernel)
+    // a group's block of C / S must stay below 2^32 dwords (the kernel keeps 32-bit dword offsets from the
+    // group's first frame and widens them when it forms the address)
     const size_t frame_bytes = (size_t)H * W1 * D * 2;
-    const int fpg_max = (int)(((size_t)1 << 32) / frame_bytes) - 1;
+    const int fpg_max = (int)(((size_t)1 << 34) / frame_bytes) - 1;
     if (fpg_max < 1) return fail(c, SV_ERR_UNSUPPORTED, "frame too large for the sweep kernel");
     if (fpg > fpg_max) fpg = fpg_max;
     n_groups = (nb + fpg - 1) / fpg;  // contiguous blocks of fpg frames; the last block may be shorter
@@ -385,7 +386,7 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     if ((rc = ensure(c, c->sw_handoff, (size_t)n_groups * (n_bands > 1 ? n_bands - 1 : 1) * (size_t)(ho_px + 1) * REC * 4))) return rc;
     if ((rc = ensure(c, c->sw_progress, (size_t)n_groups * n_bands * 4))) return rc;
     if ((rc = ensure(c, c->sw_sink, (size_t)grid * NTHR * 16))) return rc;
-    bool& attr_set = c->attr_sweep[second][N - 1][CW == 15];  // per context: the attribute is per device
+    bool& attr_set = c->attr_sweep[second][N - 1][CW == 15];  // [2][8][2]  // per context: the attribute is per device
     if (!attr_set) {
         const void* fn = second ? reinterpret_cast<const void*>(&svk::k_sweep<N, true, CW>) : reinterpret_cast<const void*>(&svk::k_sweep<N, false, CW>);
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -422,11 +423,23 @@ int launch_sweep_cw(sv_ctx* c, bool second, int nb) {
         case 2: return launch_sweep_n<2, CW>(c, second, nb);
         case 3: return launch_sweep_n<3, CW>(c, second, nb);
         case 4: return launch_sweep_n<4, CW>(c, second, nb);
-        default: return fail(c, SV_ERR_UNSUPPORTED, "fused sweeps need D <= 128");
+        default: break;
     }
+    if constexpr (CW <= 7) {  // D > 128: 8 waves per workgroup, 256 VGPRs each
+        switch (c->prm.num_disparities / 32) {
+            case 5: return launch_sweep_n<5, CW>(c, second, nb);
+            case 6: return launch_sweep_n<6, CW>(c, second, nb);
+            case 7: return launch_sweep_n<7, CW>(c, second, nb);
+            case 8: return launch_sweep_n<8, CW>(c, second, nb);
+            default: break;
+        }
+    }
+    return fail(c, SV_ERR_UNSUPPORTED, "fused sweeps need D <= 256");
 }
+// compute waves per sweep workgroup for this context's D: 15 (SV_SWEEP_CW=7: 7) up to D = 128, 7 above
+int sweep_cw_for(const sv_ctx* c) { return c->prm.num_disparities > 128 ? 7 : c->sweep_cw; }
 int launch_sweep(sv_ctx* c, bool second, int nb) {
-    return c->sweep_cw == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
+    return sweep_cw_for(c) == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
 }
 // a sweep kernel gave up waiting for its neighbour band (never expected; reported at the next sync point)
 int check_sweep_error(sv_ctx* c) {
@@ -581,10 +594,11 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         // pay the pipeline fill once per launch: they win once every pipeline streams more than one
         // frame (measured crossover at 640x480 D=128: ~40 frames on 256 CUs), below that the
         // per-path kernels are faster.
-        const int sw_rows = 4 * c->sweep_cw, sw_bands = (H + sw_rows - 1) / sw_rows;
-        const int sw_pipes = c->n_cu * (c->sweep_cw == 15 ? 1 : 2) / sw_bands;
+        const int sw_cw = sweep_cw_for(c);
+        const int sw_rows = 4 * sw_cw, sw_bands = (H + sw_rows - 1) / sw_rows;
+        const int sw_pipes = c->n_cu * ((sw_cw == 15 || D > 128) ? 1 : 2) / sw_bands;
         const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : (3 * (sw_pipes > 0 ? sw_pipes : 1) + 1) / 2;
-        const bool sweep_ok = !c->debug && D <= 128 && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= sw_min);
+        const bool sweep_ok = !c->debug && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= sw_min);
         const bool sw1 = sweep_ok && (p.path_mask & 0x0Fu) == 0x0Fu;
         const bool sw2 = sw1 && (p.path_mask & 0xF0u) == 0xF0u;
         uint32_t rest = p.path_mask;

@@ -191,12 +191,16 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     unsigned long long* const ho_out = a.handoff + ((size_t)group * (a.n_bands - 1) + max(min(band, a.n_bands - 2), 0)) * (size_t)(a.ho_px + 1) * RECQ;
     unsigned int* const flag_in = a.progress + (size_t)group * a.n_bands + max(band - 1, 0);
     unsigned int* const flag_out = a.progress + (size_t)group * a.n_bands + band;
-    unsigned long long ib[SW_DEPTH][2];
+    constexpr int NQ = (RECQ + 63) / 64;  // 8-byte words of a record per lane of the service wave (2 up to D = 128, 4 at 256)
+    unsigned long long ib[SW_DEPTH][NQ];
 #pragma unroll
-    for (int j = 0; j < SW_DEPTH; j++) ib[j][0] = ib[j][1] = 0;
-    const bool l0 = lane < RECQ, l1 = lane + 64 < RECQ;  // this lane's two 8-byte words of a record
+    for (int j = 0; j < SW_DEPTH; j++)
+#pragma unroll
+        for (int i = 0; i < NQ; i++) ib[j][i] = 0;
 
-    static_assert(N >= 1 && N <= 4, "k_sweep keeps four paths of D = 32*N disparities in registers: D <= 128");
+    static_assert(N >= 1 && (N <= 4 || (N <= 8 && CW <= 7)),
+                  "k_sweep keeps four paths of D = 32*N disparities in registers: D <= 128 with 16 waves per workgroup (128 "
+                  "VGPRs each), D <= 256 with 8 (256 VGPRs each)");
     const int tau_end = total_px + 2 * SW_ROWS + 4;
     // Two loops with the same trip count and one barrier per step each: the compute waves and the
     // service wave never share a basic block, so each body is straight-line code for the scheduler.
@@ -312,20 +316,25 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                         }
                     }
                     uint32_t* w = imp + ((t + 2) & (SW_RING - 1)) * REC;
-                    if (l0) reinterpret_cast<unsigned long long*>(w)[lane] = ib[j][0];
-                    if (l1) reinterpret_cast<unsigned long long*>(w)[lane + 64] = ib[j][1];
+#pragma unroll
+                    for (int i = 0; i < NQ; i++)
+                        if (lane + 64 * i < RECQ) reinterpret_cast<unsigned long long*>(w)[lane + 64 * i] = ib[j][i];
                     const int p = t + 6;
                     const unsigned long long* g = ho_in + (size_t)((p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
-                    if (l0) ib[j][0] = __hip_atomic_load(g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (l1) ib[j][1] = __hip_atomic_load(g + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < NQ; i++)
+                        if (lane + 64 * i < RECQ) ib[j][i] = __hip_atomic_load(g + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 // export: the record row SW_ROWS-1 wrote in the previous step (pixel t - 1 - 2*SW_ROWS)
                 if (do_export) {
                     const int p = t - 1 - 2 * SW_ROWS;
                     const uint32_t* e = expo + (p & (SW_RING - 1)) * REC;
                     unsigned long long* g = ho_out + (size_t)((p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
-                    if (l0) __hip_atomic_store(g + lane, reinterpret_cast<const unsigned long long*>(e)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (l1) __hip_atomic_store(g + lane + 64, reinterpret_cast<const unsigned long long*>(e)[lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < NQ; i++)
+                        if (lane + 64 * i < RECQ)
+                            __hip_atomic_store(g + lane + 64 * i, reinterpret_cast<const unsigned long long*>(e)[lane + 64 * i], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                     if ((t & 15) == 8) {
                         // every memory operation of this wave done (stores written through), then the counter
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -29,6 +29,9 @@ def _params(D, paths, **kw):
     (320, 240, 64, 8, svhip.FLAGS_HH, 101),   # C1: four bands
     (260, 130, 128, 5, svhip.FLAGS_REPO, 7),  # 5 paths: sweep 1 fused, path L per-path kernel; three bands
     (640, 480, 128, 8, svhip.FLAGS_HH, 202),  # C2: eight bands
+    (300, 65, 160, 8, svhip.FLAGS_REPO, 5),   # D > 128: 8-wave workgroups (28 rows per band), N = 5, three bands
+    (330, 40, 256, 8, svhip.FLAGS_HH, 6),     # D = 256, two bands (28 + 12 rows)
+    (420, 90, 224, 5, svhip.FLAGS_HH, 8),     # N = 7, 5 paths, four bands
 ])
 def test_fused_sweeps_bit_exact(gpu, W, H, D, paths, flags, seed):
     left, right, _ = synth.stereo_pair(seed, W, H, D)
@@ -69,4 +72,32 @@ def test_fused_sweeps_stream_many_frames(gpu):
     m.compute_gray_batch_dev(5, lt[2:], rt[2:], out)
     m.synchronize()
     assert np.array_equal(out[:5].cpu().numpy(), got[2:7])
+    m.close()
+
+
+def test_fused_sweeps_d256_batch(gpu):
+    """D = 256 through the production heuristics: a batch large enough for the sweeps, several frames
+    per workgroup pipeline, against the per-path kernels (which the parity tests pin to the oracle)."""
+    import torch
+    W, H, D, nb = 400, 56, 256, 9
+    ph, po = _params(D, 8)
+    pairs = [synth.stereo_pair(900 + i, W, H, D) for i in range(3)]
+    lt = torch.from_numpy(np.stack([pairs[i % 3][0] for i in range(nb)])).cuda()
+    rt = torch.from_numpy(np.stack([pairs[i % 3][1] for i in range(nb)])).cuda()
+    out = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+    os.environ["SV_SWEEP_NCU"] = "6"   # 2 bands of 28 rows -> 3 groups of 3 frames
+    try:
+        m = svhip.Matcher(W, H, ph)
+    finally:
+        del os.environ["SV_SWEEP_NCU"]
+    m.set_batch(nb)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    m.synchronize()
+    assert m.last_aggregation() == (2, 2), "the fused sweeps should have run"
+    got = out.cpu().numpy()
+    for i in range(3):
+        ref = svref.sgbm(pairs[i][0], pairs[i][1], po)
+        for k in range(i, nb, 3):
+            assert np.array_equal(got[k], ref), "frame %d differs" % k
     m.close()
