@@ -313,11 +313,12 @@ int launch_cost2_n(sv_ctx* c, int nb) {
     while ((size_t)ntx * bands * nb < (size_t)8 * c->n_cu && (H + bands) / (bands + 1) >= 24) bands++;
     const int yband = (H + bands - 1) / bands;
     const int nbands = (H + yband - 1) / yband;
-    const size_t n_wg = (size_t)ntx * nbands * ((nb + 7) / 8 * 8);
+    const bool by_xcd = nb >= 8;  // below that the frame -> XCD order would leave XCDs idle
+    const size_t n_wg = (size_t)ntx * nbands * (by_xcd ? (nb + 7) / 8 * 8 : nb);
     if (n_wg > 0x7FFFFFFFu) return fail(c, SV_ERR_UNSUPPORTED, "batch too large for one cost launch");
     hipLaunchKernelGGL((svk::k_cost2<N, NT, CN>), dim3((unsigned)n_wg), dim3(NT), lds, c->stream,
                        (const uint2*)c->stat_l.p, (const uint16_t*)c->stat_r.p, (uint32_t*)c->C.p, W, H, WP, r, yband,
-                       (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0, ntx, nbands, nb);
+                       (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0, ntx, nbands, by_xcd ? nb : -nb);
     if (H > 1)
         hipLaunchKernelGGL(svk::k_cost_col0, dim3(H - 1, nb), dim3(128), 0, c->stream, (uint32_t*)c->C.p, W1, H, D / 2,
                            (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0);

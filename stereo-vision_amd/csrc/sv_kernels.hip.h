@@ -235,9 +235,13 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     // 1-D grid, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8
     // picks the frame within a group of 8 and all column tiles of a frame (whose right-image reads
     // overlap by D + 2r columns) share one XCD's L2.
+    // Fewer than 8 frames (nframes < 0 on entry: plain order): a frame's tiles spread over all XCDs.
     const int per_frame = ntx * nbands;
-    const int wg = blockIdx.x, fr = (wg / 8 / per_frame) * 8 + (wg & 7), tb = (wg / 8) % per_frame;
-    if (fr >= nframes) return;
+    const int wg = blockIdx.x;
+    const bool by_xcd = nframes > 0;
+    const int fr = by_xcd ? (wg / 8 / per_frame) * 8 + (wg & 7) : wg / per_frame;
+    const int tb = by_xcd ? (wg / 8) % per_frame : wg % per_frame;
+    if (fr >= (by_xcd ? nframes : -nframes)) return;
     const int xl0 = (tb % ntx) * TX;
     const int y0 = (tb / ntx) * yband, y1 = min(y0 + yband, H);
     stat_l += (size_t)fr * cn * W * H;
