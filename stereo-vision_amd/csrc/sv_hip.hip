@@ -60,7 +60,7 @@ struct sv_ctx {
     int sw_prof_n = 0;
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
-    int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: 1.5 frames per workgroup pipeline
+    int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: one frame per workgroup pipeline
     bool attr_sweep[2][8][2] = {}, attr_cost2[2][8] = {};
     int sweep_cw = 15;                 // compute waves per sweep workgroup (15: one workgroup per CU, 7: two)
     int n_cu = 256;
@@ -592,13 +592,13 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     c->last_agg_launches = c->last_agg_sweeps = 0;
     {
         // The fused sweeps pipeline the bands of a frame through ceil(H / rows-per-band) workgroups and
-        // pay the pipeline fill once per launch: they win once every pipeline streams more than one
-        // frame (measured crossover at 640x480 D=128: ~40 frames on 256 CUs), below that the
-        // per-path kernels are faster.
+        // pay the pipeline fill once per launch: they win once every pipeline has a frame to stream
+        // (measured at 640x480 D=128 on 256 CUs = 32 pipelines: 24 frames 3000 vs 3060 frames/s for the
+        // per-path kernels, 32 frames 3810 vs 3100), below that the per-path kernels are faster.
         const int sw_cw = sweep_cw_for(c);
         const int sw_rows = 4 * sw_cw, sw_bands = (H + sw_rows - 1) / sw_rows;
         const int sw_pipes = c->n_cu * ((sw_cw == 15 || D > 128) ? 1 : 2) / sw_bands;
-        const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : (3 * (sw_pipes > 0 ? sw_pipes : 1) + 1) / 2;
+        const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : (sw_pipes > 0 ? sw_pipes : 1);
         const bool sweep_ok = !c->debug && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= sw_min);
         const bool sw1 = sweep_ok && (p.path_mask & 0x0Fu) == 0x0Fu;
         const bool sw2 = sw1 && (p.path_mask & 0xF0u) == 0xF0u;
