@@ -62,7 +62,7 @@ struct sv_ctx {
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: one frame per workgroup pipeline
     bool attr_sweep[2][8][2] = {}, attr_cost2[2][8] = {};
-    int sweep_cw = 15;                 // compute waves per sweep workgroup (15: one workgroup per CU, 7: two)
+    int sweep_cw = 0;                  // compute waves per sweep workgroup: 15 (one workgroup per CU), 7 (two), 0 = chosen per launch (SV_SWEEP_CW)
     int n_cu = 256;
     // concurrent paths for small batches (run_paths_fanout)
     Buf Lbuf[8];
@@ -437,10 +437,30 @@ int launch_sweep_cw(sv_ctx* c, bool second, int nb) {
     }
     return fail(c, SV_ERR_UNSUPPORTED, "fused sweeps need D <= 256");
 }
-// compute waves per sweep workgroup for this context's D: 15 (SV_SWEEP_CW=7: 7) up to D = 128, 7 above
-int sweep_cw_for(const sv_ctx* c) { return c->prm.num_disparities > 128 ? 7 : c->sweep_cw; }
+// Frame pipelines a sweep launch can keep resident: workgroup slots / bands per frame.
+int sweep_pipes(const sv_ctx* c, int cw) {
+    const int rows = 4 * cw, bands = (c->H + rows - 1) / rows;
+    const int per_cu = (cw == 15 || c->prm.num_disparities > 128) ? 1 : 2;
+    const int pipes = c->n_cu * per_cu / bands;
+    return pipes > 0 ? pipes : 1;
+}
+// Compute waves per sweep workgroup for a launch of nb frames.  D > 128 needs the 8-wave form (VGPRs).
+// Otherwise the form with the shorter predicted launch: a launch streams ceil(nb / pipelines) frames
+// of W1 steps through every pipeline after (bands - 1) * (2 * rows + 2) steps of fill.  Measured at
+// 640x480 D=128 (scratch/perf_cw.py), in units of a 16-wave streaming step: 16-wave workgroups 1.0 per
+// streaming step and 1.44 per fill step, 8-wave workgroups (two per CU) 1.063 and 0.83.
+int sweep_cw_for(const sv_ctx* c, int nb) {
+    if (c->prm.num_disparities > 128) return 7;
+    if (c->sweep_cw) return c->sweep_cw;
+    const int W1 = c->W - c->prm.num_disparities;
+    auto cost = [&](int cw, double stream, double fill) {
+        const int rows = 4 * cw, bands = (c->H + rows - 1) / rows, pipes = sweep_pipes(c, cw);
+        return (double)((nb + pipes - 1) / pipes) * W1 * stream + (double)(bands - 1) * (2 * rows + 2) * fill;
+    };
+    return cost(7, 1.063, 0.83) < cost(15, 1.0, 1.44) ? 7 : 15;
+}
 int launch_sweep(sv_ctx* c, bool second, int nb) {
-    return sweep_cw_for(c) == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
+    return sweep_cw_for(c, nb) == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
 }
 // a sweep kernel gave up waiting for its neighbour band (never expected; reported at the next sync point)
 int check_sweep_error(sv_ctx* c) {
@@ -595,10 +615,10 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         // pay the pipeline fill once per launch: they win once every pipeline has a frame to stream
         // (measured at 640x480 D=128 on 256 CUs = 32 pipelines: 24 frames 3000 vs 3060 frames/s for the
         // per-path kernels, 32 frames 3810 vs 3100), below that the per-path kernels are faster.
-        const int sw_cw = sweep_cw_for(c);
-        const int sw_rows = 4 * sw_cw, sw_bands = (H + sw_rows - 1) / sw_rows;
-        const int sw_pipes = c->n_cu * ((sw_cw == 15 || D > 128) ? 1 : 2) / sw_bands;
-        const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : (sw_pipes > 0 ? sw_pipes : 1);
+        // (with the 8-wave form chosen for small launches: from 3/4 of its pipelines, 21 frames there)
+        const int sw_pipes = sweep_pipes(c, sweep_cw_for(c, nb));
+        const int sw_auto = (D > 128 || c->sweep_cw) ? sw_pipes : (3 * sweep_pipes(c, 7) + 3) / 4;
+        const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : sw_auto;
         const bool sweep_ok = !c->debug && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= sw_min);
         const bool sw1 = sweep_ok && (p.path_mask & 0x0Fu) == 0x0Fu;
         const bool sw2 = sw1 && (p.path_mask & 0xF0u) == 0xF0u;
@@ -727,7 +747,7 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     if (const char* e = getenv("SV_FUSE_WTA_MIN_BATCH")) c->fuse_wta_min_batch = atoi(e);  // tuning knobs
     if (const char* e = getenv("SV_SWEEP_MIN_BATCH")) c->sweep_min_batch = atoi(e);
     if (const char* e = getenv("SV_SWEEP_MODE")) c->sweep_mode = atoi(e);
-    if (const char* e = getenv("SV_SWEEP_CW")) c->sweep_cw = atoi(e) == 7 ? 7 : 15;
+    if (const char* e = getenv("SV_SWEEP_CW")) c->sweep_cw = atoi(e) == 7 ? 7 : (atoi(e) == 15 ? 15 : 0);
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("SV_SWEEP_NCU")) c->n_cu = atoi(e) > 0 ? atoi(e) : c->n_cu;  // tests: few groups, many frames each
     HIPCHK(c, hipHostMalloc((void**)&c->sw_error, sizeof(unsigned int), hipHostMallocMapped));
