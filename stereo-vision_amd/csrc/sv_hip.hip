@@ -39,7 +39,7 @@ struct sv_ctx {
 
     // device buffers
     Buf img_l, img_r;        // u8 [H][W] staging for the host entry points
-    Buf stat_l, stat_r;      // left: uint2 [H][W] records; right: u16 planes [6][2][H][pitch]
+    Buf stat_l, stat_r;      // left: uint2 [H][W] records; right: u16 planes [3][2][H][pitch], two 8-bit statistics per element
     Buf C, S;                // u16 [H][W1][D]
     Buf rec;                 // WTA records {disp16, raw, minS, 0} [H][W] x 8 bytes
     bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
@@ -164,8 +164,8 @@ int alloc_core(sv_ctx* c) {
     int rc;
     const size_t cn = (c->prm.flags & SV_FLAG_COST_RGB) ? 3 : 1;  // statistics per colour plane
     if ((rc = ensure(c, c->stat_l, npx * 8 * cn))) return rc;
-    // right statistics: six u16 planes x two copies (k_stats_planes)
-    if ((rc = ensure(c, c->stat_r, (size_t)12 * c->H * svk::cost_plane_pitch(c->W) * 2 * c->batch * cn))) return rc;
+    // right statistics: three u16 planes (two 8-bit statistics each) x two copies (k_stats_planes)
+    if ((rc = ensure(c, c->stat_r, (size_t)6 * c->H * svk::cost_plane_pitch(c->W) * 2 * c->batch * cn))) return rc;
     if ((rc = ensure(c, c->C, nvol * 2))) return rc;
     if ((rc = ensure(c, c->S, nvol * 2))) return rc;
     if ((rc = ensure(c, c->rec, npx * 8))) return rc;

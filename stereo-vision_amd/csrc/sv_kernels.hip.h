@@ -152,12 +152,15 @@ __device__ __forceinline__ int raw_at(const uint8_t* __restrict__ img, int W, in
 // k_stats_planes writes the LEFT statistics as 8-byte records {g, g0, g1, r, r0, r1} (g = clipped
 // Sobel-x value, r = raw channel with its edge columns forced to ftzero, a0/a1 = min/max of
 // {a, (a+left)/2, (a+right)/2}: what get_pixel_diff recomputes per disparity) and the RIGHT
-// statistics as six planes of u16, reversed in x (index i = W-1-x), each in two copies (the second
-// shifted by one element): a lane that needs the right statistics of x-d for 2N consecutive
-// disparities reads them as N aligned dwords per plane straight from L1/L2 - (stat(x-d),
-// stat(x-d-1)) is already the packed pair the 16-bit VALU wants.  No per-row staging of the right
-// image in LDS, no unpacking, one barrier per image row instead of three.
-// Plane layout: rp[frame][stat 0..5][copy 0..1][H][WP] u16, WP even, >= W + 2.
+// statistics as three planes of u16, reversed in x (index i = W-1-x), each in two copies (the
+// second shifted by one element); an element holds a gradient statistic in its low byte and the
+// matching raw statistic in its high byte ((g, r), (g0, r0), (g1, r1)).  A lane that needs the right
+// statistics of x-d for 2N consecutive disparities reads N aligned dwords per plane straight from
+// L1/L2; (elem(x-d), elem(x-d-1)) is the packed pair the 16-bit VALU wants after one v_and (low
+// bytes) or one v_perm (high bytes).  No per-row staging of the right image in LDS, one barrier per
+// image row instead of three.  (Unpacked u16 planes, one statistic each, cost twice the L1 traffic
+// and 15 % more time in k_cost2.)
+// Plane layout: rp[frame][pair 0..2][copy 0..1][H][WP] u16, WP even, >= W + 2.
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline int cost_plane_pitch(int W) { return (W + 2 + 7) & ~7; }
 
@@ -193,13 +196,13 @@ __global__ __launch_bounds__(256) void k_stats_planes(const uint8_t* __restrict_
         stat_l[(size_t)fc * W * H + (size_t)y * W + x] =
             make_uint2((uint32_t)g | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)r << 24), (uint32_t)r0 | ((uint32_t)r1 << 8));
     } else {
-        const int st[6] = {g, g0, g1, r, r0, r1};
+        const int st[3] = {g | (r << 8), g0 | (r0 << 8), g1 | (r1 << 8)};  // gradient statistic low byte, raw high byte
         const int i = W - 1 - x;
-        uint16_t* base = rp + (size_t)fc * 12 * H * WP + (size_t)y * WP;
+        uint16_t* base = rp + (size_t)fc * 6 * H * WP + (size_t)y * WP;
 #pragma unroll
-        for (int s6 = 0; s6 < 6; s6++) {
-            base[(size_t)(2 * s6) * H * WP + i] = (uint16_t)st[s6];
-            if (i >= 1) base[(size_t)(2 * s6 + 1) * H * WP + i - 1] = (uint16_t)st[s6];
+        for (int s3 = 0; s3 < 3; s3++) {
+            base[(size_t)(2 * s3) * H * WP + i] = (uint16_t)st[s3];
+            if (i >= 1) base[(size_t)(2 * s3 + 1) * H * WP + i - 1] = (uint16_t)st[s3];
         }
     }
 }
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     const int xl0 = (tb % ntx) * TX;
     const int y0 = (tb / ntx) * yband, y1 = min(y0 + yband, H);
     stat_l += (size_t)fr * cn * W * H;
-    const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)fr * cn * 12 * H * WP);
+    const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)fr * cn * 6 * H * WP);
     C += (size_t)fr * H * W1 * D2;
     // BT item of this thread: tile column j (clamped into the computable band), disparities 2N*q ..
     const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + D;
@@ -259,15 +262,15 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     uint32_t* const myring = ring + j * D2 + q * N;
 
     uint2 lrec;
-    uint32_t rs[6][N];
+    uint32_t rq[3][N];  // right statistics as loaded: per u16 the gradient statistic in the low byte, the raw one in the high byte
     auto prefetch = [&](int ry, int ch) {
         ry = min(ry, H - 1);
         lrec = stat_l[(size_t)ch * W * H + (size_t)ry * W + xj];
 #pragma unroll
-        for (int s6 = 0; s6 < 6; s6++)
-            load_regs<N>(rbase + (size_t)(12 * ch + 2 * s6) * plane + (size_t)ry * (WP / 2), rs[s6]);
+        for (int s3 = 0; s3 < 3; s3++)
+            load_regs<N>(rbase + (size_t)(6 * ch + 2 * s3) * plane + (size_t)ry * (WP / 2), rq[s3]);
     };
-    // BT costs of image row ry, summed over the cn colour planes (operands of plane 0 in lrec / rs,
+    // BT costs of image row ry, summed over the cn colour planes (operands of plane 0 in lrec / rq,
     // prefetched) -> pix[ry & 1]; while a plane is computed the operands of the next plane, or of
     // plane 0 of the next row, are on their way.
     auto bt_store = [&](int ry) {
@@ -280,8 +283,13 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
             const uint32_t ug1 = ((lrec.x >> 16) & 0xFFu) * 0x10001u, ur = (lrec.x >> 24) * 0x10001u;
             const uint32_t ur0 = (lrec.y & 0xFFu) * 0x10001u, ur1 = ((lrec.y >> 8) & 0xFFu) * 0x10001u;
 #pragma unroll
-            for (int k = 0; k < N; k++)  // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
-                pv[k] += bt_pk2(ug, ug0, ug1, rs[0][k], rs[1][k], rs[2][k]) + ((bt_pk2(ur, ur0, ur1, rs[3][k], rs[4][k], rs[5][k]) >> 2) & 0x3FFF3FFFu);
+            for (int k = 0; k < N; k++) {  // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
+                // unpack: one v_and / one v_perm per statistic and register (half the L1 traffic of unpacked planes)
+                const uint32_t vg = rq[0][k] & 0x00FF00FFu, vg0 = rq[1][k] & 0x00FF00FFu, vg1 = rq[2][k] & 0x00FF00FFu;
+                const uint32_t vr = __builtin_amdgcn_perm(0u, rq[0][k], 0x0C030C01u), vr0 = __builtin_amdgcn_perm(0u, rq[1][k], 0x0C030C01u);
+                const uint32_t vr1 = __builtin_amdgcn_perm(0u, rq[2][k], 0x0C030C01u);
+                pv[k] += bt_pk2(ug, ug0, ug1, vg, vg0, vg1) + ((bt_pk2(ur, ur0, ur1, vr, vr0, vr1) >> 2) & 0x3FFF3FFFu);
+            }
             if (ch + 1 < cn) prefetch(ry, ch + 1);
             else prefetch(ry + 1, 0);
         }
