@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
                 const uint32_t vg = rq[0][k] & 0x00FF00FFu, vg0 = rq[1][k] & 0x00FF00FFu, vg1 = rq[2][k] & 0x00FF00FFu;
                 const uint32_t vr = __builtin_amdgcn_perm(0u, rq[0][k], 0x0C030C01u), vr0 = __builtin_amdgcn_perm(0u, rq[1][k], 0x0C030C01u);
                 const uint32_t vr1 = __builtin_amdgcn_perm(0u, rq[2][k], 0x0C030C01u);
-                pv[k] += bt_pk2(ug, ug0, ug1, vg, vg0, vg1) + ((bt_pk2(ur, ur0, ur1, vr, vr0, vr1) >> 2) & 0x3FFF3FFFu);
+                pv[k] += bt_pk2(ug, ug0, ug1, vg, vg0, vg1) + __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, bt_pk2(ur, ur0, ur1, vr, vr0, vr1)) >> 2);
             }
             if (ch + 1 < cn) prefetch(ry, ch + 1);
             else prefetch(ry + 1, 0);
