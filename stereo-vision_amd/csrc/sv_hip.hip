@@ -61,7 +61,7 @@ struct sv_ctx {
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: one frame per workgroup pipeline
-    bool attr_sweep[2][8][2] = {}, attr_cost2[2][8] = {};
+    bool attr_sweep[2][8][2] = {}, attr_cost2[2][2][8] = {};
     int sweep_cw = 0;                  // compute waves per sweep workgroup: 15 (one workgroup per CU), 7 (two), 0 = chosen per launch (SV_SWEEP_CW)
     int n_cu = 256;
     // concurrent paths for small batches (run_paths_fanout)
@@ -292,15 +292,20 @@ int run_paths_fanout(sv_ctx* c, int nb) {
     return SV_OK;
 }
 
-template <int N, int CN>
+template <int N, int CN, int NT = 512>
 int launch_cost2_n(sv_ctx* c, int nb) {
     // CN = colour planes in the cost: 1 (gray) or 3 (SV_FLAG_COST_RGB)
-    constexpr int NT = 512, NCOL = NT / 16;
+    constexpr int NCOL = NT / 16;
     const sv_params& p = c->prm;
     const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
     const int TX = NCOL - 2 * r, WP = svk::cost_plane_pitch(W);
     const size_t lds = (size_t)(2 * NCOL + (2 * r + 2) * TX) * (16 * N) * 4;
-    bool* attr_set = c->attr_cost2[CN == 3];  // per context: the attribute is per device
+    if (lds > 160 * 1024) {
+        // D = 256 with an 11 x 11 block: the 12-row ring of a 32-column tile is 164 KB.  24 tile columns fit.
+        if constexpr (NT == 512 && N == 8) return launch_cost2_n<N, CN, 384>(c, nb);
+        return fail(c, SV_ERR_UNSUPPORTED, "cost kernel tile of %zu bytes exceeds the 160 KB of LDS", lds);
+    }
+    bool* attr_set = c->attr_cost2[CN == 3][NT != 512];  // per context: the attribute is per device
     if (lds > 48 * 1024 && !attr_set[N - 1]) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_cost2<N, NT, CN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024));

@@ -143,3 +143,33 @@ def test_async_submit_wait(gpu):
     with pytest.raises(svhip.SvError):
         m.wait(tickets[2])                                 # already collected
     m.close()
+
+
+def test_random_geometries_all_variants(gpu):
+    """Seeded random image sizes, disparity ranges, block sizes, path sets and flags - small, ragged, narrow
+    and short ones included - through every aggregation variant (production choice, per-path launches,
+    all paths in one launch, fused sweeps of both workgroup shapes) against the oracle, bit-exact."""
+    rng = np.random.default_rng(20240611)
+    n = 0
+    while n < 28:
+        D = int(rng.choice([32, 64, 96, 128, 160, 224, 256]))
+        bs = int(rng.choice([1, 3, 5, 7, 9, 11]))
+        paths = int(rng.choice([5, 8]))
+        flags = int(rng.choice([svhip.FLAGS_REPO, svhip.FLAGS_HH]))
+        W = D + bs + int(rng.integers(0, 140))
+        H = bs + int(rng.integers(0, 150))
+        cap = int(rng.choice([15, 31, 63]))
+        uniq = int(rng.choice([0, 5, 15, 40]))
+        P1, P2 = 8 * bs * bs, 32 * bs * bs
+        if (2 * cap + 63) * bs * bs + P2 > 32767:
+            continue
+        n += 1
+        left, right, _ = synth.stereo_pair(1000 + n, W, H, D)
+        ph, po = _params(D, paths, flags=flags, block_size=bs, P1=P1, P2=P2, pre_filter_cap=cap, uniqueness_ratio=uniq)
+        ref = svref.sgbm(left, right, po)
+        what = "W=%d H=%d D=%d bs=%d paths=%d flags=%#x cap=%d uniq=%d" % (W, H, D, bs, paths, flags, cap, uniq)
+        m = svhip.Matcher(W, H, ph)
+        for mode in (0, 4, 5, 3):
+            m.set_debug(mode)
+            assert np.array_equal(m.compute_gray(left, right), ref), "%s, debug mode %d" % (what, mode)
+        m.close()
