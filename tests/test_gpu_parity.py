@@ -173,3 +173,28 @@ def test_random_geometries_all_variants(gpu):
             m.set_debug(mode)
             assert np.array_equal(m.compute_gray(left, right), ref), "%s, debug mode %d" % (what, mode)
         m.close()
+
+
+@pytest.mark.parametrize("name", ["synthetic_64x48_d32", "icub_320x240_d64", "view_463x370_d96"])
+def test_golden_fixtures_on_gpu(gpu, name):
+    """The committed fixtures (tests/golden/: the reference's own sample images, sgbm_cuda/lefti.png etc.,
+    with the parameters of sgbm_cuda/main.cpp:47-54) read as data, not through the oracle: final
+    disparity16 and the CRC of every stage, on every aggregation variant."""
+    import os
+    import zlib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    D, paths = int(g["D"]), int(g["paths"])
+    ph = svhip.default_params(D, paths, flags=int(g["flags"]), uniqueness_ratio=int(g["uniq"]), disp12_max_diff=int(g["disp12"]))
+    left, right = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+    m = svhip.Matcher(left.shape[1], left.shape[0], ph)
+    for mode in (0, 2, 3, 4, 5):
+        m.set_debug(mode)
+        assert np.array_equal(m.compute_gray(left, right), g["disp16"]), "debug mode %d" % mode
+    m.set_debug(True)
+    assert np.array_equal(m.compute_gray(left, right), g["disp16"])
+    assert crc(m.debug_volume(0)) == int(g["crc_C"])
+    assert crc(m.debug_volume(1)) == int(g["crc_S"])
+    assert crc(m.debug_plane(0)) == int(g["crc_disp_wta"])
+    assert crc(m.debug_plane(3)) == int(g["crc_disp_lr"])
+    m.close()
