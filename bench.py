@@ -148,7 +148,7 @@ def main():
     B = args.batch if args.config != "c4" else min(args.batch, 96)  # C4: 1.84 GB of volumes per pair (96 pairs = 177 GB)
     params = svhip.default_params(D, paths)  # SAD 7, P1 8*49, P2 32*49, cap 63, uniq 15, LR check on
     n_distinct = min(B, 64)   # 64 distinct pairs per stream, looped
-    seed0 = 202 if world == 1 else 500 + 16 * rank
+    seed0 = 202 if world == 1 else 500 + 64 * rank
     pairs = [synth.stereo_pair(seed0 + i, W, H, D) for i in range(n_distinct)]
     lefts = [p[0] for p in pairs]
     rights = [p[1] for p in pairs]
