@@ -74,6 +74,12 @@ __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {  // eac
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
+// signed saturating packed add (v_pk_add_i16 clamp): for operands in [0, 32767] each half = min(a + b, 32767),
+// the S accumulation rule of aggregation.cu:135-139 in one instruction
+__device__ __forceinline__ uint32_t pk_add_sat15(uint32_t a, uint32_t b) {
+    typedef short ss2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b)));
+}
 
 template <int N>
 __device__ __forceinline__ void load_regs(const uint32_t* __restrict__ p, uint32_t (&r)[N]) {
@@ -581,7 +587,7 @@ __device__ __forceinline__ void agg_body(const uint32_t* __restrict__ C, uint32_
             uint32_t L = pk_sub(c[k], pk_sub_sat(dd, t));
             r[k] = L;
             mn = pk_min(mn, L);
-            snew[k] = FIRST ? L : pk_min(pk_add(s[k], L), 0x7FFF7FFFu);
+            snew[k] = FIRST ? L : pk_add_sat15(s[k], L);
         }
         mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // both halves = lane minimum
         mn = row16_min_u32(mn);
@@ -707,10 +713,8 @@ __global__ __launch_bounds__(256) void k_sum_wta(PathBufs pb, uint2* __restrict_
     for (int i = 1; i < pb.n; i++) {
         load_regs<N>(pb.L[i] + off, v);
 #pragma unroll
-        for (int k = 0; k < N; k++) acc[k] = pk_add_sat(acc[k], v[k]);
+        for (int k = 0; k < N; k++) acc[k] = pk_add_sat15(acc[k], v[k]);
     }
-#pragma unroll
-    for (int k = 0; k < N; k++) acc[k] = pk_min(acc[k], 0x7FFF7FFFu);
     rec[((size_t)blockIdx.y * H + y) * W + xl + D] = wta_record<N>(acc, q, make_uniq(uniq));
 }
 

@@ -254,11 +254,11 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 uint32_t snew[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) {
-                    // every L <= 32767, so the pair sums cannot wrap; the rest saturates at 65535 and
-                    // is clamped once: min(S + L, 32767) applied path by path gives the same value
-                    uint32_t s4 = pk_add_sat(pk_add(L0[k], L1[k]), pk_add(L2[k], L3[k]));
-                    if (SECOND) s4 = pk_add_sat(s4, sb[j][k]);
-                    snew[k] = pk_min(s4, 0x7FFF7FFFu);
+                    // every term is in [0, 32767]: signed saturating adds clamp at 32767, and
+                    // min(S + L, 32767) applied path by path gives the same value in any grouping
+                    uint32_t s4 = pk_add_sat15(pk_add_sat15(L0[k], L1[k]), pk_add_sat15(L2[k], L3[k]));
+                    if (SECOND) s4 = pk_add_sat15(s4, sb[j][k]);
+                    snew[k] = s4;
                     r0[k] = L0[k];
                 }
                 dd0 = n0;
