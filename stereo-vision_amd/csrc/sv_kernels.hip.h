@@ -51,6 +51,34 @@ __device__ __forceinline__ uint32_t row16_min_u32(uint32_t v) {
     asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
     return o;
 }
+// Four all-row minima in 10 DPP operations instead of 16: a is reduced to every lane of the row
+// (the butterfly of row16_min_u32); b, c and d are reduced jointly, each stage keeping a value only
+// in the quads (bank_mask = groups of 4 lanes) that go on with it: after the two cross-quad stages
+// quad 0 holds b, quads 1 and 3 hold d and quad 2 holds c, and the two intra-quad stages finish
+// them there.  zq = min b in lanes 0-3, min d in lanes 4-7 and 12-15, min c in lanes 8-11.
+// Hand-scheduled: two other instructions (or an s_nop) between a VALU write and the DPP read of it.
+__device__ __forceinline__ void row16_min_1p3(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t& a_all, uint32_t& zq) {
+    uint32_t x, y, z, t;
+    asm("s_nop 1\n\t"
+        "v_min_u32_dpp %0, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_min_u32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_min_u32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %3, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_min_u32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(t)
+        : "v"(a), "v"(b), "v"(c), "v"(d));
+    a_all = t;
+    zq = z;
+}
 __device__ __forceinline__ uint32_t row16_or_u32(uint32_t v) {
     v |= dpp<DPP_QUAD_XOR1>(0u, v);
     v |= dpp<DPP_QUAD_XOR2>(0u, v);

@@ -66,7 +66,7 @@ __host__ __device__ constexpr size_t sweep_lds_bytes() {
 // KEEP = false (sweep 2, which has no registers to spare) re-initialises them every step instead.
 template <int N, bool KEEP>
 __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&r)[N], uint32_t dd, uint32_t P1P1,
-                                           uint32_t P2P2, uint32_t (&L)[N], uint32_t& dd_out, uint32_t (&edge)[2]) {
+                                           uint32_t (&L)[N], uint32_t& mn_out, uint32_t (&edge)[2]) {
     if (KEEP) {
         edge[0] = dpp<DPP_ROW_SHR1>(edge[0], r[N - 1]);
         edge[1] = dpp<DPP_ROW_SHL1>(edge[1], r[0]);
@@ -85,9 +85,7 @@ __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_
         L[k] = pk_sub(c[k], pk_sub_sat(dd, t));
         mn = pk_min(mn, L[k]);
     }
-    mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));
-    mn = row16_min_u32(mn);
-    dd_out = mn + P2P2;
+    mn_out = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // this lane's minimum in both halves; the row's: row16_min_1p3
 }
 
 #ifdef SV_SWEEP_PROF
@@ -234,15 +232,19 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     dd_dl = st_r ? P2P2 : dd_dl;
                 }
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
-                sweep_path<N, !SECOND>(cb[j], r0, dd0, P1P1, P2P2, L0, n0, edge[0]);                  // horizontal
-                sweep_path<N, !SECOND>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, P2P2, L1, n1, edge[1]);   // from (x-1, y-1): read two steps ago
-                sweep_path<N, !SECOND>(cb[j], dn, dn_dd, P1P1, P2P2, L2, n2, edge[2]);               // from (x,   y-1): read last step
-                sweep_path<N, !SECOND>(cb[j], in_dl, dd_dl, P1P1, P2P2, L3, n3, edge[3]);            // from (x+1, y-1): read now
+                sweep_path<N, !SECOND>(cb[j], r0, dd0, P1P1, L0, n0, edge[0]);                  // horizontal
+                sweep_path<N, !SECOND>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, L1, n1, edge[1]);   // from (x-1, y-1): read two steps ago
+                sweep_path<N, !SECOND>(cb[j], dn, dn_dd, P1P1, L2, n2, edge[2]);               // from (x,   y-1): read last step
+                sweep_path<N, !SECOND>(cb[j], in_dl, dd_dl, P1P1, L3, n3, edge[3]);            // from (x+1, y-1): read now
+                // min over d of every path: the horizontal one into every lane (this row's next step), the
+                // other three only into the record (tail words 0-3: path 3, 4-7: path 2, 8-11: path 1)
+                uint32_t nq;
+                row16_min_1p3(n0, n3, n1, n2, n0, nq);
                 // the parts of this step's record that are used later go straight into their registers
                 load_regs<N>(src + PXW + q * N, dn);
                 load_regs<N>(src + 2 * PXW + q * N, dr[j & 1]);
-                dn_dd = src[3 * PXW + 1];
-                dr_dd[j & 1] = src[3 * PXW + 2];
+                dn_dd = src[3 * PXW + 4];
+                dr_dd[j & 1] = src[3 * PXW + 8];
                 SW_STAMP(T2)
                 // own record for the row below
                 uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
@@ -250,7 +252,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 store_regs<N>(dst + q * N, L3);
                 store_regs<N>(dst + PXW + q * N, L2);
                 store_regs<N>(dst + 2 * PXW + q * N, L1);
-                dst[3 * PXW + q] = q == 0 ? n3 : (q == 1 ? n2 : n1);  // words 3.. of the tail are padding
+                dst[3 * PXW + q] = nq + P2P2;
                 uint32_t snew[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     snew[k] = s4;
                     r0[k] = L0[k];
                 }
-                dd0 = n0;
+                dd0 = n0 + P2P2;
                 if (SECOND) {
                     // The reductions leave the same three words in all 16 lanes of the row's group;
                     // lane (step mod 16) keeps them, and once per 16 steps every lane finishes the
