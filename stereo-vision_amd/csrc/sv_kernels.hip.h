@@ -425,13 +425,18 @@ __global__ __launch_bounds__(256) void k_cost_col0(uint32_t* __restrict__ C, int
 // The uniqueness test "S[d]*(100-uniq) < minS*100" is done as S[d] < T with
 // T = ceil(minS*100 / (100-uniq)), the division by the (uniform) constant through a magic multiply.
 struct UniqK {
-    int mul;         // 100 - uniquenessRatio
-    uint32_t magic;  // floor(2^32 / mul) + 1 (exact for numerators < 2^22), unused when mul == 0
+    uint32_t k, add, magic;  // T = umulhi(minS * k + add, magic), branch-free for every ratio
 };
 __device__ __forceinline__ UniqK make_uniq(int uniq) {
+    const int mul = 100 - uniq;  // 100 - uniquenessRatio
     UniqK u;
-    u.mul = 100 - uniq;
-    u.magic = u.mul > 0 ? 0xFFFFFFFFu / (uint32_t)u.mul + 1u : 0u;
+    if (mul > 1) {  // ceil(minS*100 / mul): magic = floor(2^32 / mul) + 1 is exact for numerators < 2^22
+        u.k = 100u; u.add = (uint32_t)mul - 1u; u.magic = 0xFFFFFFFFu / (uint32_t)mul + 1u;
+    } else if (mul == 1) {  // minS*100 itself (the magic of 1 would be 2^32): floor((200 minS + 1) / 2)
+        u.k = 200u; u.add = 1u; u.magic = 0x80000000u;
+    } else {        // ratio 100: every S counts as soon as minS > 0: T = (minS << 16) - 1 >= 0xFFFF, or 0
+        u.k = 0x10000u; u.add = 0u; u.magic = 0xFFFFFFFFu;
+    }
     return u;
 }
 
@@ -441,8 +446,7 @@ struct WtaPart {
     uint32_t nb;   // S[best-1] << 16 | S[best+1] (0 where there is no such disparity)
 };
 __device__ __forceinline__ uint32_t wta_threshold(uint32_t minS, UniqK uq) {
-    const uint32_t thr = minS * 100u;
-    return uq.mul > 0 ? __umulhi(thr + (uint32_t)uq.mul - 1u, uq.magic) : (thr > 0u ? 0x10000u : 0u);
+    return __umulhi(minS * uq.k + uq.add, uq.magic);
 }
 
 template <int N>
@@ -459,28 +463,32 @@ __device__ __forceinline__ WtaPart wta_reduce(const uint32_t (&s)[N], int q, Uni
     const int best = (int)(key & 0xFFFFu);
     // uniqueness: no S outside best-1..best+1 may be below T.  Every S lies in [0, 32767], so with T
     // clamped to 32768 "S < T" is the sign of the 16-bit difference: count the hits over all
-    // disparities (3 packed instructions per register); wta_finish compares the count with the hits
+    // disparities; wta_finish compares the count with the hits
     // among the three exempt positions.
     const uint32_t T = wta_threshold(key >> 16, uq);
     const uint32_t Tc = min(T, 0x8000u), TT = Tc | (Tc << 16);
-    us2 hits = {0, 0};
+    // sign bits of two registers' differences gathered into one word (v_perm), counted by v_bcnt
+    uint32_t cnt = 0;
 #pragma unroll
-    for (int k = 0; k < N; k++) hits += (__builtin_bit_cast(us2, s[k]) - __builtin_bit_cast(us2, TT)) >> 15;
-    uint32_t cnt = __builtin_bit_cast(uint32_t, hits);
-    cnt = row16_add_u32((cnt & 0xFFFFu) + (cnt >> 16));
+    for (int k = 0; k + 1 < N; k += 2) {
+        const uint32_t g = __builtin_amdgcn_perm(pk_sub(s[k], TT), pk_sub(s[k + 1], TT), 0x07050301u);
+        cnt += (uint32_t)__builtin_popcount(g & 0x80808080u);
+    }
+    if (N & 1) cnt += (uint32_t)__builtin_popcount(pk_sub(s[N - 1], TT) & 0x80008000u);
+    cnt = row16_add_u32(cnt);
     // S[best-1] and S[best+1]: positions p and p+2 of the owning lane, 0 elsewhere, OR-reduced.
     // Both have the parity of p and sit in registers kq = p >> 1 and kq + 1 (either may lie outside
     // this lane: then the neighbouring lane supplies the value).
     const int p = best - 1 - dbase;  // position of best-1 in this lane's 2N values (may lie outside)
     const int kq = p >> 1;
-    const uint32_t hsel = (uint32_t)(p & 1) << 4;
     uint32_t vm = 0u, vp = 0u;
 #pragma unroll
     for (int k = 0; k < N; k++) {
         vm = kq == k ? s[k] : vm;
         vp = kq == k - 1 ? s[k] : vp;
     }
-    uint32_t nb = (__builtin_amdgcn_ubfe(vm, hsel, 16) << 16) | __builtin_amdgcn_ubfe(vp, hsel, 16);
+    // the low (p even) or high (p odd) halves of both: S[best-1] into the high half, S[best+1] into the low half
+    uint32_t nb = __builtin_amdgcn_perm(vm, vp, (p & 1) ? 0x07060302u : 0x05040100u);
     nb = row16_or_u32(nb);
     // best < 256 and the count only matters up to 4 (at most three positions are exempt): both fit the low half
     return WtaPart{key | (min(cnt, 255u) << 8), nb};

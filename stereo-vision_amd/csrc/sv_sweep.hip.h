@@ -59,20 +59,15 @@ __host__ __device__ constexpr size_t sweep_lds_bytes() {
 // One SGM path update of one pixel: r = previous L along the path (0 with dd = P2 when the path
 // starts here), c = the pixel's costs.  Same arithmetic as k_agg's step:
 //   L = C + min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1, dd) - dd  =  C - max(dd - a, 0).
-// edge[0] / edge[1] receive the neighbour lanes' registers through DPP row shifts.  The lane with no
-// neighbour (0 resp. 15 of the row) keeps what the register held before: "no such disparity" =
-// 0x7FFF7FFF, set once before the loop and never overwritten there, so the same register is shifted
-// into every step without being re-initialised (two moves per path and step saved).
-// KEEP = false (sweep 2, which has no registers to spare) re-initialises them every step instead.
-template <int N, bool KEEP>
+// The neighbour lanes' registers arrive through DPP row shifts folded into an OR (v_or_b32_dpp with
+// bound_ctrl: the lane with no neighbour reads 0) with a per-lane constant: "no such disparity" =
+// 0x7FFF7FFF in lane 0 (big15: lane 15) of the row, 0 elsewhere.  One instruction per shift, no landing
+// register to initialise or keep.
+template <int N>
 __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&r)[N], uint32_t dd, uint32_t P1P1,
-                                           uint32_t (&L)[N], uint32_t& mn_out, uint32_t (&edge)[2]) {
-    if (KEEP) {
-        edge[0] = dpp<DPP_ROW_SHR1>(edge[0], r[N - 1]);
-        edge[1] = dpp<DPP_ROW_SHL1>(edge[1], r[0]);
-    }
-    const uint32_t prevHi = KEEP ? edge[0] : dpp<DPP_ROW_SHR1>(0x7FFF7FFFu, r[N - 1]);
-    const uint32_t nextLo = KEEP ? edge[1] : dpp<DPP_ROW_SHL1>(0x7FFF7FFFu, r[0]);
+                                           uint32_t (&L)[N], uint32_t& mn_out, uint32_t big0, uint32_t big15) {
+    const uint32_t prevHi = big0 | dpp<DPP_ROW_SHR1>(0u, r[N - 1]);
+    const uint32_t nextLo = big15 | dpp<DPP_ROW_SHL1>(0u, r[0]);
     uint32_t m[N + 1];
     m[0] = __builtin_amdgcn_alignbit(r[0], prevHi, 16);
 #pragma unroll
@@ -159,9 +154,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     const UniqK uqk = make_uniq(a.uniq);
     WtaPart stash = {0u, 0u};              // sweep 2: reduced WTA words of the pixel this lane will finish
     uint32_t stash_rq = 0xFFFFFFFFu;       // ... and its record index (all ones: nothing kept)
-    uint32_t edge[4][2];  // per path: DPP landing registers of sweep_path
-#pragma unroll
-    for (int k = 0; k < 4; k++) edge[k][0] = edge[k][1] = 0x7FFF7FFFu;
+    const uint32_t big0 = q == 0 ? 0x7FFF7FFFu : 0u, big15 = q == 15 ? 0x7FFF7FFFu : 0u;  // see sweep_path
     uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH], recq[SW_DEPTH];
     uint32_t lrbase = 0;                             // index of frame lfi's first WTA record
     const uint32_t rowrec = (uint32_t)yp * a.W + 32 * N, frame_px = (uint32_t)H * a.W;
@@ -232,10 +225,10 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     dd_dl = st_r ? P2P2 : dd_dl;
                 }
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
-                sweep_path<N, !SECOND>(cb[j], r0, dd0, P1P1, L0, n0, edge[0]);                  // horizontal
-                sweep_path<N, !SECOND>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, L1, n1, edge[1]);   // from (x-1, y-1): read two steps ago
-                sweep_path<N, !SECOND>(cb[j], dn, dn_dd, P1P1, L2, n2, edge[2]);               // from (x,   y-1): read last step
-                sweep_path<N, !SECOND>(cb[j], in_dl, dd_dl, P1P1, L3, n3, edge[3]);            // from (x+1, y-1): read now
+                sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal
+                sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, L1, n1, big0, big15);   // from (x-1, y-1): read two steps ago
+                sweep_path<N>(cb[j], dn, dn_dd, P1P1, L2, n2, big0, big15);               // from (x,   y-1): read last step
+                sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, L3, n3, big0, big15);            // from (x+1, y-1): read now
                 // min over d of every path: the horizontal one into every lane (this row's next step), the
                 // other three only into the record (tail words 0-3: path 3, 4-7: path 2, 8-11: path 1)
                 uint32_t nq;

@@ -198,3 +198,18 @@ def test_golden_fixtures_on_gpu(gpu, name):
     assert crc(m.debug_plane(0)) == int(g["crc_disp_wta"])
     assert crc(m.debug_plane(3)) == int(g["crc_disp_lr"])
     m.close()
+
+
+@pytest.mark.parametrize("uniq", [100, 99, 50, 1])
+def test_uniqueness_ratio_extremes(gpu, uniq):
+    """Uniqueness ratios at the ends of the accepted range (100: every pixel with minS > 0 is rejected),
+    every aggregation variant."""
+    W, H, D = 150, 61, 64
+    left, right, _ = synth.stereo_pair(12, W, H, D)
+    ph, po = _params(D, 8, uniqueness_ratio=uniq)
+    ref = svref.sgbm(left, right, po)
+    m = svhip.Matcher(W, H, ph)
+    for mode in (0, 2, 3, 4, 5):
+        m.set_debug(mode)
+        assert np.array_equal(m.compute_gray(left, right), ref), "debug mode %d" % mode
+    m.close()
