@@ -97,6 +97,9 @@ __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_
 #define SW_PROF(...)
 #endif
 
+#ifndef SW_EARLY_FENCE
+#define SW_EARLY_FENCE __builtin_amdgcn_sched_barrier(0);
+#endif
 __device__ __forceinline__ void sweep_barrier() {
     // LDS traffic of this wave done, then the workgroup barrier.  Not __syncthreads(): that would
     // also drain vmcnt and with it the global-load pipeline.
@@ -225,9 +228,19 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     dd_dl = st_r ? P2P2 : dd_dl;
                 }
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
-                sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal
+                // Own record for the row below.  Its three L parts leave as soon as each is computed: a 16-byte
+                // LDS store occupies the store path for ~13 cycles per wave, 15 waves x 3 of them bunched in
+                // front of the barrier would leave the VALUs idle for that long; issued early they overlap with
+                // the other waves' arithmetic.  (The row below reads this buffer only after the barrier.)
+                uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
+                                                   : slot + ((j & 1) * (SW_ROWS + 1) + r + 1) * REC;
                 sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, L1, n1, big0, big15);   // from (x-1, y-1): read two steps ago
+                store_regs<N>(dst + 2 * PXW + q * N, L1);
+                SW_EARLY_FENCE
                 sweep_path<N>(cb[j], dn, dn_dd, P1P1, L2, n2, big0, big15);               // from (x,   y-1): read last step
+                store_regs<N>(dst + PXW + q * N, L2);
+                SW_EARLY_FENCE
+                sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal
                 sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, L3, n3, big0, big15);            // from (x+1, y-1): read now
                 // min over d of every path: the horizontal one into every lane (this row's next step), the
                 // other three only into the record (tail words 0-3: path 3, 4-7: path 2, 8-11: path 1)
@@ -239,12 +252,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 dn_dd = src[3 * PXW + 4];
                 dr_dd[j & 1] = src[3 * PXW + 8];
                 SW_STAMP(T2)
-                // own record for the row below
-                uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
-                                                   : slot + ((j & 1) * (SW_ROWS + 1) + r + 1) * REC;
                 store_regs<N>(dst + q * N, L3);
-                store_regs<N>(dst + PXW + q * N, L2);
-                store_regs<N>(dst + 2 * PXW + q * N, L1);
                 dst[3 * PXW + q] = nq + P2P2;
                 uint32_t snew[N];
 #pragma unroll
