@@ -240,8 +240,10 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 sweep_path<N>(cb[j], dn, dn_dd, P1P1, L2, n2, big0, big15);               // from (x,   y-1): read last step
                 store_regs<N>(dst + PXW + q * N, L2);
                 SW_EARLY_FENCE
-                sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal
                 sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, L3, n3, big0, big15);            // from (x+1, y-1): read now
+                store_regs<N>(dst + q * N, L3);
+                SW_EARLY_FENCE
+                sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal: stays in registers
                 // min over d of every path: the horizontal one into every lane (this row's next step), the
                 // other three only into the record (tail words 0-3: path 3, 4-7: path 2, 8-11: path 1)
                 uint32_t nq;
@@ -252,7 +254,6 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 dn_dd = src[3 * PXW + 4];
                 dr_dd[j & 1] = src[3 * PXW + 8];
                 SW_STAMP(T2)
-                store_regs<N>(dst + q * N, L3);
                 dst[3 * PXW + q] = nq + P2P2;
                 uint32_t snew[N];
 #pragma unroll
