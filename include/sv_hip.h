@@ -157,6 +157,31 @@ int sv_submit_gray_host(sv_ctx* ctx, const uint8_t* left_host, size_t left_strid
                         const uint8_t* right_host, size_t right_stride, int* ticket);
 int sv_wait_host(sv_ctx* ctx, int ticket, int16_t* disp16_host, size_t disp_stride);
 
+/* Many pairs per call through host buffers, for hosts that serve several camera
+ * streams (BASELINE.json configs[4]; DispModule itself handles one pair per
+ * updateModule(), DispModule.cpp:661-814).  sv_submit_gray_batch_host enqueues,
+ * for n_frames <= sv_set_batch pairs given as arrays of per-frame pointers
+ * (frames of different streams live in different buffers): the uploads on a copy
+ * stream of the context, one batched matcher launch on the context stream, and
+ * the downloads into disp16_host[i] on a second copy stream; it returns a ticket
+ * at once.  SV_BATCH_SLOTS batches may be in flight, so the PCIe traffic of batch
+ * k+1 and k-1 overlaps the kernels of batch k.  Nothing is staged: the copies
+ * run at PCIe speed and asynchronously when the buffers are pinned
+ * (sv_host_alloc, or hipHostMalloc / hipHostRegister by the caller) and through
+ * the runtime's own staging otherwise.  All buffers, inputs and outputs, must
+ * stay valid and untouched until sv_wait_batch_host(ticket) returns; tickets are
+ * waited for in the order they were issued.  No counterpart in the reference,
+ * which blocks on every copy (bova_sgm.cu:87-136).                            */
+#define SV_BATCH_SLOTS 2
+int sv_submit_gray_batch_host(sv_ctx* ctx, int n_frames, const uint8_t* const* left_host, size_t left_stride,
+                              const uint8_t* const* right_host, size_t right_stride,
+                              int16_t* const* disp16_host, size_t disp_stride, int* ticket);
+int sv_wait_batch_host(sv_ctx* ctx, int ticket);
+/* Pinned (page-locked) host memory for the buffers above, for hosts that do not
+ * link the HIP runtime themselves.                                            */
+int sv_host_alloc(void** ptr, size_t bytes);
+int sv_host_free(void* ptr);
+
 /* Same path with inputs and output already resident in HBM (dense rows:
  * stride = width resp. 2*width bytes).  Asynchronous on the context stream.   */
 int sv_compute_gray_dev(sv_ctx* ctx, const uint8_t* left_dev, const uint8_t* right_dev,

@@ -55,6 +55,15 @@ struct sv_ctx {
     } slot[N_SLOTS];
     bool slots_ok = false;
     long next_ticket = 0;
+    // batched asynchronous host pipeline (sv_submit_gray_batch_host / sv_wait_batch_host)
+    struct BatchSlot {
+        Buf in_l, in_r, out;      // device: [n][H][W] u8 x 2, [n][H][W] i16
+        hipEvent_t up = nullptr, computed = nullptr, done = nullptr;
+        bool busy = false;
+    } bslot[SV_BATCH_SLOTS];
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    bool bslots_ok = false;
+    long next_batch_ticket = 0;
     // fused four-path sweeps (sv_sweep.hip.h)
     Buf sw_handoff, sw_progress, sw_sink, sw_prof;
     int sw_prof_n = 0;
@@ -780,6 +789,16 @@ int sv_destroy(sv_ctx* c) {
                     if (sl.done) (void)hipEventDestroy(sl.done);
                 }
             for (int i = 0; i < 8; i++) release(c->Lbuf[i]);
+            if (c->bslots_ok) {
+                if (c->up_stream) { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamDestroy(c->up_stream); }
+                if (c->down_stream) { (void)hipStreamSynchronize(c->down_stream); (void)hipStreamDestroy(c->down_stream); }
+                for (auto& b : c->bslot) {
+                    release(b.in_l); release(b.in_r); release(b.out);
+                    if (b.up) (void)hipEventDestroy(b.up);
+                    if (b.computed) (void)hipEventDestroy(b.computed);
+                    if (b.done) (void)hipEventDestroy(b.done);
+                }
+            }
 
             if (c->ev_ok)
                 for (int r = 0; r < sv_ctx::EV_RING; r++)
@@ -961,6 +980,86 @@ int sv_wait_host(sv_ctx* c, int ticket, int16_t* disp16, size_t ds) {
     sl.busy = false;
     return check_sweep_error(c);
 }
+
+int sv_submit_gray_batch_host(sv_ctx* c, int n_frames, const uint8_t* const* left, size_t ls, const uint8_t* const* right, size_t rs,
+                              int16_t* const* disp16, size_t ds, int* ticket) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!left || !right || !disp16 || !ticket) return fail(c, SV_ERR_INVALID_ARG, "NULL pointer");
+    if (n_frames < 1 || n_frames > c->batch)
+        return fail(c, SV_ERR_INVALID_ARG, "n_frames %d outside [1, batch=%d] (sv_set_batch)", n_frames, c->batch);
+    const size_t W = c->W, H = c->H, n = n_frames;
+    if (ls < W || rs < W || ds < 2 * W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    for (size_t i = 0; i < n; i++)
+        if (!left[i] || !right[i] || !disp16[i]) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer (frame %zu)", i);
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    if (!c->bslots_ok) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+        for (auto& b : c->bslot) {
+            HIPCHK(c, hipEventCreateWithFlags(&b.up, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&b.computed, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+        }
+        c->bslots_ok = true;
+    }
+    sv_ctx::BatchSlot& b = c->bslot[c->next_batch_ticket % SV_BATCH_SLOTS];
+    if (b.busy) return fail(c, SV_ERR_INVALID_ARG, "%d batches already in flight: sv_wait_batch_host the oldest ticket first", SV_BATCH_SLOTS);
+    int rc;
+    // the slot's device buffers were last used by a batch that has been waited for
+    if ((rc = ensure(c, b.in_l, n * W * H))) return rc;
+    if ((rc = ensure(c, b.in_r, n * W * H))) return rc;
+    if ((rc = ensure(c, b.out, n * W * H * 2))) return rc;
+    // Uploads.  Frames that follow each other densely in host memory (one array of frames) travel as one copy.
+    auto upload = [&](const uint8_t* const* img, size_t stride, uint8_t* dst) -> hipError_t {
+        for (size_t i = 0; i < n;) {
+            size_t j = i + 1;
+            if (stride == W)
+                while (j < n && img[j] == img[j - 1] + W * H) j++;
+            hipError_t e = copy2d(dst + i * W * H, W, img[i], stride, W, H * (stride == W ? j - i : 1), hipMemcpyHostToDevice, c->up_stream);
+            if (e != hipSuccess) return e;
+            i = stride == W ? j : i + 1;
+        }
+        return hipSuccess;
+    };
+    HIPCHK(c, upload(left, ls, (uint8_t*)b.in_l.p));
+    HIPCHK(c, upload(right, rs, (uint8_t*)b.in_r.p));
+    HIPCHK(c, hipEventRecord(b.up, c->up_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, b.up, 0));
+    if ((rc = run_sgm(c, (const uint8_t*)b.in_l.p, (const uint8_t*)b.in_r.p, (int16_t*)b.out.p, n_frames))) return rc;
+    HIPCHK(c, hipEventRecord(b.computed, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->down_stream, b.computed, 0));
+    for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        if (ds == 2 * W)
+            while (j < n && disp16[j] == disp16[j - 1] + W * H) j++;
+        HIPCHK(c, copy2d(disp16[i], ds, (const int16_t*)b.out.p + i * W * H, 2 * W, 2 * W, H * (ds == 2 * W ? j - i : 1), hipMemcpyDeviceToHost,
+                         c->down_stream));
+        i = ds == 2 * W ? j : i + 1;
+    }
+    HIPCHK(c, hipEventRecord(b.done, c->down_stream));
+    b.busy = true;
+    *ticket = (int)(c->next_batch_ticket++ & 0x7FFFFFFF);
+    return SV_OK;
+}
+
+int sv_wait_batch_host(sv_ctx* c, int ticket) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!c->bslots_ok || ticket < 0) return fail(c, SV_ERR_INVALID_ARG, "unknown batch ticket %d", ticket);
+    sv_ctx::BatchSlot& b = c->bslot[ticket % SV_BATCH_SLOTS];
+    const long newest = (c->next_batch_ticket - 1) & 0x7FFFFFFF;
+    if (!b.busy || (long)ticket > newest || newest - ticket >= SV_BATCH_SLOTS) return fail(c, SV_ERR_INVALID_ARG, "batch ticket %d is not in flight", ticket);
+    DevGuard g(c->device);
+    HIPCHK(c, hipEventSynchronize(b.done));
+    b.busy = false;
+    return check_sweep_error(c);
+}
+
+int sv_host_alloc(void** ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return SV_ERR_INVALID_ARG;
+    return hipHostMalloc(ptr, bytes, hipHostMallocDefault) == hipSuccess ? SV_OK : SV_ERR_NOMEM;
+}
+int sv_host_free(void* ptr) { return hipHostFree(ptr) == hipSuccess ? SV_OK : SV_ERR_HIP; }
 
 int sv_gray_from_rgb_dev(sv_ctx* c, const uint8_t* rgb_dev, uint8_t* gray_dev) {
     if (!c) return SV_ERR_INVALID_ARG;

@@ -27,7 +27,7 @@ TIMING_NAMES = ("prefilter", "cost", "aggregation", "wta", "tail", "total")
 
 EXPORTS = (
     "sv_default_params", "sv_create", "sv_destroy", "sv_set_params", "sv_get_params", "sv_set_stream",
-    "sv_compute_gray_host", "sv_submit_gray_host", "sv_wait_host", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
+    "sv_compute_gray_host", "sv_submit_gray_host", "sv_wait_host", "sv_submit_gray_batch_host", "sv_wait_batch_host", "sv_host_alloc", "sv_host_free", "sv_compute_gray_dev", "sv_set_batch", "sv_compute_gray_batch_dev", "sv_gray_from_rgb_dev", "sv_upload_maps_host",
     "sv_remap_rgb_dev", "sv_compute_rgb_host", "sv_get_rectified_host", "sv_disparity_vis_dev",
     "sv_disparity_vis_host", "sv_filter_speckles_dev", "sv_depth_host", "sv_depth_dev",
     "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_filter_blf_joint_dev", "sv_filter_blf_joint_host", "sv_compute_rgb_batch_dev", "sv_disparity_vis_batch_dev", "sv_depth_batch_dev", "sv_world_image_dev", "sv_world_image_host",
@@ -88,6 +88,10 @@ def load():
     L.sv_compute_gray_host.argtypes = [vp, vp, sz, vp, sz, vp, sz]
     L.sv_submit_gray_host.argtypes = [vp, vp, sz, vp, sz, C.POINTER(C.c_int)]
     L.sv_wait_host.argtypes = [vp, i32, vp, sz]
+    L.sv_submit_gray_batch_host.argtypes = [vp, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, C.POINTER(vp), sz, C.POINTER(C.c_int)]
+    L.sv_wait_batch_host.argtypes = [vp, i32]
+    L.sv_host_alloc.argtypes = [C.POINTER(vp), sz]
+    L.sv_host_free.argtypes = [vp]
     L.sv_compute_gray_dev.argtypes = [vp, vp, vp, vp]
     L.sv_set_batch.argtypes = [vp, i32]
     L.sv_compute_gray_batch_dev.argtypes = [vp, i32, vp, vp, vp]
@@ -210,6 +214,23 @@ class Matcher:
         t = C.c_int()
         self._chk(self._L.sv_submit_gray_host(self._h, _ptr(left), self.W, _ptr(right), self.W, C.byref(t)))
         return t.value
+
+    def submit_gray_batch(self, lefts, rights, outs, left_stride=None, right_stride=None, out_stride=None):
+        """Asynchronous batch through host buffers (sv_submit_gray_batch_host): lefts / rights / outs are
+        sequences of per-frame addresses (ints) or numpy arrays; every buffer must stay alive and untouched
+        until wait_batch(ticket).  Strides in bytes (default: dense rows)."""
+        n = len(lefts)
+        addr = lambda a: a if isinstance(a, int) else a.ctypes.data
+        pl = (C.c_void_p * n)(*[addr(a) for a in lefts])
+        pr = (C.c_void_p * n)(*[addr(a) for a in rights])
+        po = (C.c_void_p * n)(*[addr(a) for a in outs])
+        t = C.c_int()
+        self._chk(self._L.sv_submit_gray_batch_host(self._h, n, pl, left_stride or self.W, pr, right_stride or self.W,
+                                                    po, out_stride or 2 * self.W, C.byref(t)))
+        return t.value
+
+    def wait_batch(self, ticket):
+        self._chk(self._L.sv_wait_batch_host(self._h, ticket))
 
     def wait(self, ticket):
         out = np.empty((self.H, self.W), np.int16)
@@ -406,3 +427,28 @@ class Matcher:
 
     def gray_from_rgb_dev(self, rgb_t, gray_t):
         self._chk(self._L.sv_gray_from_rgb_dev(self._h, C.c_void_p(rgb_t.data_ptr()), C.c_void_p(gray_t.data_ptr())))
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory from sv_host_alloc (freed with free() or when collected)."""
+
+    def __init__(self, shape, dtype):
+        self._L = load()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = C.c_void_p()
+        rc = self._L.sv_host_alloc(C.byref(self._p), self.nbytes)
+        if rc:
+            raise SvError(rc, "sv_host_alloc(%d bytes)" % self.nbytes)
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(self.nbytes,)).view(dtype).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            self._L.sv_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -213,3 +213,49 @@ def test_uniqueness_ratio_extremes(gpu, uniq):
         m.set_debug(mode)
         assert np.array_equal(m.compute_gray(left, right), ref), "debug mode %d" % mode
     m.close()
+
+
+def test_async_batch_host(gpu):
+    """sv_submit_gray_batch_host / sv_wait_batch_host: two batches in flight, pageable and pinned buffers,
+    scattered frames, one dense array of frames and padded rows; every frame equal to the synchronous entry point."""
+    W, H, D, nb = 200, 90, 64, 5
+    ph, _ = _params(D, 8)
+    m = svhip.Matcher(W, H, ph)
+    m.set_batch(nb)
+    pairs = [synth.stereo_pair(60 + i, W, H, D) for i in range(2 * nb)]
+    refs = [m.compute_gray(p[0], p[1]) for p in pairs]
+    # batch A: scattered pageable frames; batch B: one pinned array of frames (dense: merged copies)
+    outs_a = [np.full((H, W), 777, np.int16) for _ in range(nb)]
+    pin_l, pin_r = svhip.PinnedArray((nb, H, W), np.uint8), svhip.PinnedArray((nb, H, W), np.uint8)
+    pin_o = svhip.PinnedArray((nb, H, W), np.int16)
+    for i in range(nb):
+        pin_l.array[i], pin_r.array[i] = pairs[nb + i][:2]
+    pin_o.array[:] = 777
+    ta = m.submit_gray_batch([p[0] for p in pairs[:nb]], [p[1] for p in pairs[:nb]], outs_a)
+    tb = m.submit_gray_batch([pin_l.array[i] for i in range(nb)], [pin_r.array[i] for i in range(nb)], [pin_o.array[i] for i in range(nb)])
+    with pytest.raises(svhip.SvError):
+        m.submit_gray_batch([pairs[0][0]], [pairs[0][1]], [outs_a[0]])   # both slots in flight
+    m.wait_batch(ta)
+    for i in range(nb):
+        assert np.array_equal(outs_a[i], refs[i]), "batch A frame %d" % i
+    m.wait_batch(tb)
+    for i in range(nb):
+        assert np.array_equal(pin_o.array[i], refs[nb + i]), "batch B frame %d" % i
+    with pytest.raises(svhip.SvError):
+        m.wait_batch(tb)                                                    # already collected
+    # padded rows (a YARP image: rows padded to 8 bytes; here stride W + 24) and a smaller batch
+    ls = W + 24
+    padl, padr = np.zeros((3, H, ls), np.uint8), np.zeros((3, H, ls), np.uint8)
+    pado = np.full((3, H, ls), 777, np.int16)
+    for i in range(3):
+        padl[i, :, :W], padr[i, :, :W] = pairs[i][:2]
+    t = m.submit_gray_batch([padl[i] for i in range(3)], [padr[i] for i in range(3)], [pado[i] for i in range(3)],
+                            left_stride=ls, right_stride=ls, out_stride=2 * ls)
+    m.wait_batch(t)
+    for i in range(3):
+        assert np.array_equal(pado[i, :, :W], refs[i]) and (pado[i, :, W:] == 777).all()
+    with pytest.raises(svhip.SvError):
+        m.submit_gray_batch([p[0] for p in pairs[:nb + 1]], [p[1] for p in pairs[:nb + 1]], outs_a + [outs_a[0]])  # > sv_set_batch
+    for a in (pin_l, pin_r, pin_o):
+        a.free()
+    m.close()
