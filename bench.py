@@ -137,9 +137,23 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
+        # RCCL carries only the timing barrier and the max-over-ranks; if it cannot come up on this node the
+        # same two operations go over gloo (host tensors) rather than losing the measurement
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            probe = torch.zeros(1, device="cuda")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            backend = "nccl"
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("bench: RCCL unavailable (%s); barrier over gloo\n" % str(e)[:200])
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo")
+            backend = "gloo"
 
     import svhip
     from svhip import synth
@@ -202,7 +216,7 @@ def main():
     stage_ms = m.timings()
     m.enable_timing(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
