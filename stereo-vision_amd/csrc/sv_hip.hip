@@ -70,7 +70,7 @@ struct sv_ctx {
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: one frame per workgroup pipeline
-    bool attr_sweep[2][8][2] = {}, attr_cost2[2][2][8] = {};
+    bool attr_sweep[2][8][2] = {}, attr_cost2[2][2][8] = {}, attr_lrcheck = false;
     int sweep_cw = 0;                  // compute waves per sweep workgroup: 15 (one workgroup per CU), 7 (two), 0 = chosen per launch (SV_SWEEP_CW)
     int n_cu = 256;
     // concurrent paths for small batches (run_paths_fanout)
@@ -138,8 +138,9 @@ int check_params(sv_ctx* c, const sv_params* p, int W, int H) {
         return fail(c, SV_ERR_UNSUPPORTED, "num_disparities must be a multiple of 32 in [32,256] (got %d)", D);
     if (BS < 1 || BS > 11 || (BS % 2) == 0)
         return fail(c, SV_ERR_UNSUPPORTED, "block_size must be odd in [1,11] (got %d)", BS);
-    if (W <= D || H < BS || W - D < BS || W > 65535 || H > 65535)
-        return fail(c, SV_ERR_INVALID_ARG, "image %dx%d too small/large for D=%d block=%d", W, H, D, BS);
+    // width: the LR check keeps one 4-byte key per column of a row in LDS (160 KB)
+    if (W <= D || H < BS || W - D < BS || W > 40000 || H > 65535)
+        return fail(c, SV_ERR_INVALID_ARG, "image %dx%d too small/large for D=%d block=%d (W <= 40000, H <= 65535)", W, H, D, BS);
     if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63)
         return fail(c, SV_ERR_UNSUPPORTED, "pre_filter_cap must be in [1,63] (got %d)", p->pre_filter_cap);
     if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return fail(c, SV_ERR_INVALID_ARG, "need 0 <= P1 <= P2, P2 >= 1");
@@ -692,6 +693,10 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         int thr = p.disp12_max_diff;
         if (p.flags & SV_FLAG_LR_OPENCV) thr = thr > 0 ? thr : 1;
         if (p.flags & SV_FLAG_NO_LRCHECK) thr = 1 << 20;
+        if ((size_t)W * 4 > 48 * 1024 && !c->attr_lrcheck) {
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_lrcheck), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            c->attr_lrcheck = true;
+        }
         hipLaunchKernelGGL(svk::k_lrcheck, dim3(H, nb), dim3(256), (size_t)W * 4, c->stream, (const uint2*)c->rec.p,
                            (int16_t*)c->disp_lr.p, W, D, thr);
     }

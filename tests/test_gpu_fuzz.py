@@ -95,3 +95,23 @@ def test_c2_batch_through_production_sweeps(gpu):
     for i in range(nb):
         assert np.array_equal(got[i], refs[i % nd]), "frame %d differs" % i
     m.close()
+
+
+@pytest.mark.parametrize("W,H,D", [(200, 8000, 32), (40000, 8, 32), (40, 65535, 32), (2049, 1537, 256)])
+def test_extreme_geometries(gpu, W, H, D):
+    """Very tall (more row bands than CUs), widest and tallest accepted, and a large ragged D=256 frame:
+    production choice, per-path launches and forced sweeps against the oracle."""
+    left, right, _ = synth.stereo_pair(7, W, H, D)
+    ph, po = _params(D, 8)
+    ref = svref.sgbm(left, right, po)
+    m = svhip.Matcher(W, H, ph)
+    for mode in (0, 4, 3):
+        m.set_debug(mode)
+        assert np.array_equal(m.compute_gray(left, right), ref), "debug mode %d" % mode
+    m.close()
+
+
+def test_too_wide_is_rejected(gpu):
+    with pytest.raises(svhip.SvError) as e:
+        svhip.Matcher(40001, 8, svhip.default_params(32, 8))
+    assert e.value.code == -1   # SV_ERR_INVALID_ARG
