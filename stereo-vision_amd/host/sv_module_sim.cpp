@@ -42,6 +42,10 @@ int main(int argc, char** argv) {
     int frames = argc > 4 ? atoi(argv[4]) : 20, paths = argc > 5 ? atoi(argv[5]) : 8;
     const bool wls = argc > 6 && atoi(argv[6]) != 0;  // --wls (DispModule.cpp:259-265)
     const int blf = argc > 7 ? atoi(argv[7]) : 0;     // 1 = --blf BLF_ORIGINAL, 2 = --cuda_blf BLF_CUDA (DispModule.cpp:253-258)
+    if (W <= 0 || H <= 0 || D <= 0 || frames < 2 || (paths != 5 && paths != 8)) {
+        fprintf(stderr, "usage: sv_module_sim [width height numDisp frames(>=2) paths(5|8) wls(0|1) blf(0|1|2)]\n");
+        return 1;
+    }
     StereoCamera cam;
     StereoMatcherNew matcher(&cam);
     matcher.paths = paths;
@@ -59,7 +63,7 @@ int main(int argc, char** argv) {
     cam.setQ(Q);
 
     double total_ms = 0;
-    long valid = 0, npx = 0;
+    long valid = 0, npx = 0, ndepth = 0;
     double depth_sum = 0;
     for (int i = 0; i < frames; i++) {
         Image L, R;
@@ -78,13 +82,17 @@ int main(int argc, char** argv) {
         for (int y = 0; y < H; y++)
             for (int x = D; x < W; x++) {
                 npx++;
-                if (d16.ptr<int16_t>(y)[x] >= 0) { valid++; depth_sum += depth.ptr<float>(y)[x]; }
+                if (d16.ptr<int16_t>(y)[x] >= 0) {
+                    valid++;
+                    const float z = depth.ptr<float>(y)[x];
+                    if (z > 0.0f && z < 1e6f) { depth_sum += z; ndepth++; }  // disparity 0 reprojects to infinity
+                }
             }
         (void)vis;
     }
     printf("sv_module_sim: %dx%d D=%d paths=%d frames=%d  host-buffer path %.3f ms/frame (%.1f fps, PCIe-inclusive, "
            "synchronous)  valid %.1f%%  mean depth %.3f m\n",
            W, H, D, paths, frames, total_ms / (frames > 1 ? frames - 1 : 1), 1000.0 * (frames - 1) / (total_ms > 0 ? total_ms : 1),
-           100.0 * valid / (npx ? npx : 1), valid ? depth_sum / valid : 0.0);
+           100.0 * valid / (npx ? npx : 1), ndepth ? depth_sum / ndepth : 0.0);
     return 0;
 }
