@@ -616,7 +616,7 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         const int groups = (W + 3) / 4;
         const int T = groups + 2 <= 256 ? ((groups + 2 + 63) / 64) * 64 : 256;
         const int span = 4 * (T - 2);
-        hipLaunchKernelGGL(svk::k_stats_planes, dim3((W + span - 1) / span, H, 2 * nb * cn), dim3(T), 0, c->stream, left, right,
+        hipLaunchKernelGGL(svk::k_stats_planes, dim3((W + span - 1) / span, (H + svk::STATS_ROWS - 1) / svk::STATS_ROWS, 2 * nb * cn), dim3(T), 0, c->stream, left, right,
                            (uint2*)c->stat_l.p, (uint16_t*)c->stat_r.p, W, H, svk::cost_plane_pitch(W), p.pre_filter_cap, cn);
     }
     mark();

@@ -214,90 +214,103 @@ __device__ __forceinline__ void stat_minmax(int a, int lo, int hi, bool has_lo, 
     a0 = min(min(al, ah), a);
     a1 = max(max(al, ah), a);
 }
+constexpr int STATS_ROWS = 8;   // image rows per block: a row's three source rows are loaded once and kept in registers
 __global__ __launch_bounds__(256) void k_stats_planes(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                        uint2* __restrict__ stat_l, uint16_t* __restrict__ rp, int W, int H, int WP,
                                                        int cap, int cn) {
-    __shared__ uint16_t gr_lds[4 * 256 + 4];
+    __shared__ uint16_t gr_lds[2][4 * 256 + 4];
     const int T = blockDim.x, t = threadIdx.x;
     const int e0 = (int)blockIdx.x * 4 * (T - 2) - 4 + 4 * t;   // first element of this thread (halo groups: t = 0, T-1)
-    const int y = blockIdx.y;
+    const int ya = blockIdx.y * STATS_ROWS, yb = min(ya + STATS_ROWS, H);
     const int fc = blockIdx.z >> 1, frame = fc / cn, ch = fc - frame * cn;
     const bool is_right = blockIdx.z & 1;
     const uint8_t* img = (is_right ? right : left) + (size_t)frame * W * H * cn + ch;
-    const uint8_t* r0 = img + (size_t)y * W * cn;
-    const uint8_t* rm = img + (size_t)max(y - 1, 0) * W * cn;
-    const uint8_t* rq = img + (size_t)min(y + 1, H - 1) * W * cn;
-    // Sobel-x column sums of the six pixels around the group (clamped reads; values outside the image are never used)
-    int col[6], raw[6];
+    const bool writer = t != 0 && t != T - 1 && e0 < W;
+    // the six pixels around the group (clamped reads; values outside the image are never used): rows y-1, y, y+1
+    int xc[6], am[6], a0[6], ap[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const int e = e0 - 1 + k, x = is_right ? W - 1 - e : e;
-        const int xc = min(max(x, 0), W - 1) * cn;
-        raw[k] = r0[xc];
-        col[k] = 2 * raw[k] + (int)rm[xc] + (int)rq[xc];
+        xc[k] = min(max(x, 0), W - 1) * cn;
+        am[k] = img[(size_t)max(ya - 1, 0) * W * cn + xc[k]];
+        a0[k] = img[(size_t)ya * W * cn + xc[k]];
     }
     const int sgn = is_right ? -1 : 1;  // element e+1 is pixel x-1 in the reversed order
+    for (int y = ya; y < yb; y++) {
+        uint16_t* gr = gr_lds[(y - ya) & 1];
+        const uint8_t* rq = img + (size_t)min(y + 1, H - 1) * W * cn;
+        int col[6];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int e = e0 + k, x = is_right ? W - 1 - e : e;
-        const bool edge = x <= 0 || x >= W - 1;
-        const int g = edge ? cap : min(max(sgn * (col[k + 2] - col[k]), -cap), cap) + cap;
-        const int r = edge ? cap : raw[k + 1];
-        gr_lds[4 * t + k] = (uint16_t)(g | (r << 8));
-    }
-    __syncthreads();
-    if (t == 0 || t == T - 1 || e0 >= W) return;
-    // statistics of elements e0 .. e0+4 from gr of e0-1 .. e0+5
-    int gv[7], rv[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const int v = gr_lds[4 * t - 1 + k];
-        gv[k] = v & 0xFF;
-        rv[k] = v >> 8;
-    }
-    uint32_t st[3][5];   // per element: (g, r), (g0, r0), (g1, r1) as gradient | raw << 8
-    uint2 rec[4];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int e = e0 + k;
-        const bool has_lo = e > 0, has_hi = e < W - 1;  // a neighbour on either side (symmetric: the order does not matter)
-        int g0, g1, q0, q1;
-        stat_minmax(gv[k + 1], gv[k], gv[k + 2], has_lo, has_hi, g0, g1);
-        stat_minmax(rv[k + 1], rv[k], rv[k + 2], has_lo, has_hi, q0, q1);
-        st[0][k] = (uint32_t)(gv[k + 1] | (rv[k + 1] << 8));
-        st[1][k] = (uint32_t)(g0 | (q0 << 8));
-        st[2][k] = (uint32_t)(g1 | (q1 << 8));
-        if (k < 4)
-            rec[k] = make_uint2((uint32_t)gv[k + 1] | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)rv[k + 1] << 24),
-                                (uint32_t)q0 | ((uint32_t)q1 << 8));
-    }
-    if (!is_right) {
-        const size_t off = (size_t)fc * W * H + (size_t)y * W + e0;
-        uint2* out = stat_l + off;
-        if (e0 + 3 < W && (off & 1) == 0) {   // four records, 16-byte aligned
-            reinterpret_cast<uint4*>(out)[0] = make_uint4(rec[0].x, rec[0].y, rec[1].x, rec[1].y);
-            reinterpret_cast<uint4*>(out)[1] = make_uint4(rec[2].x, rec[2].y, rec[3].x, rec[3].y);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (e0 + k < W) out[k] = rec[k];
+        for (int k = 0; k < 6; k++) {
+            ap[k] = rq[xc[k]];
+            col[k] = 2 * a0[k] + am[k] + ap[k];   // Sobel-x column sum
         }
-    } else {
-        uint16_t* base = rp + (size_t)fc * 6 * H * WP + (size_t)y * WP + e0;   // e0 is a multiple of 4, WP of 8: 8-byte aligned
 #pragma unroll
-        for (int s3 = 0; s3 < 3; s3++) {
-            uint16_t* c0 = base + (size_t)(2 * s3) * H * WP;       // copy 0: element i at index i       (i <= W-1)
-            uint16_t* c1 = base + (size_t)(2 * s3 + 1) * H * WP;   // copy 1: element i at index i - 1   (indices 0 .. W-2)
-            if (e0 + 3 < W) *reinterpret_cast<uint2*>(c0) = make_uint2(st[s3][0] | (st[s3][1] << 16), st[s3][2] | (st[s3][3] << 16));
-            else
+        for (int k = 0; k < 4; k++) {
+            const int e = e0 + k, x = is_right ? W - 1 - e : e;
+            const bool edge = x <= 0 || x >= W - 1;
+            const int g = edge ? cap : min(max(sgn * (col[k + 2] - col[k]), -cap), cap) + cap;
+            const int r = edge ? cap : a0[k + 1];
+            gr[4 * t + k] = (uint16_t)(g | (r << 8));
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { am[k] = a0[k]; a0[k] = ap[k]; }
+        // one barrier per row: this row's values go to the buffer the row before last used, whose readers
+        // passed the previous row's barrier
+        __syncthreads();
+        if (!writer) continue;
+        // statistics of elements e0 .. e0+4 from gr of e0-1 .. e0+5
+        int gv[7], rv[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const int v = gr[4 * t - 1 + k];
+            gv[k] = v & 0xFF;
+            rv[k] = v >> 8;
+        }
+        uint32_t st[3][5];   // per element: (g, r), (g0, r0), (g1, r1) as gradient | raw << 8
+        uint2 rec[4];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int e = e0 + k;
+            const bool has_lo = e > 0, has_hi = e < W - 1;  // a neighbour on either side (symmetric: the order does not matter)
+            int g0, g1, q0, q1;
+            stat_minmax(gv[k + 1], gv[k], gv[k + 2], has_lo, has_hi, g0, g1);
+            stat_minmax(rv[k + 1], rv[k], rv[k + 2], has_lo, has_hi, q0, q1);
+            st[0][k] = (uint32_t)(gv[k + 1] | (rv[k + 1] << 8));
+            st[1][k] = (uint32_t)(g0 | (q0 << 8));
+            st[2][k] = (uint32_t)(g1 | (q1 << 8));
+            if (k < 4)
+                rec[k] = make_uint2((uint32_t)gv[k + 1] | ((uint32_t)g0 << 8) | ((uint32_t)g1 << 16) | ((uint32_t)rv[k + 1] << 24),
+                                    (uint32_t)q0 | ((uint32_t)q1 << 8));
+        }
+        if (!is_right) {
+            const size_t off = (size_t)fc * W * H + (size_t)y * W + e0;
+            uint2* out = stat_l + off;
+            if (e0 + 3 < W && (off & 1) == 0) {   // four records, 16-byte aligned
+                reinterpret_cast<uint4*>(out)[0] = make_uint4(rec[0].x, rec[0].y, rec[1].x, rec[1].y);
+                reinterpret_cast<uint4*>(out)[1] = make_uint4(rec[2].x, rec[2].y, rec[3].x, rec[3].y);
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (e0 + k < W) c0[k] = (uint16_t)st[s3][k];
-            if (e0 + 4 < W) *reinterpret_cast<uint2*>(c1) = make_uint2(st[s3][1] | (st[s3][2] << 16), st[s3][3] | (st[s3][4] << 16));
-            else
+                    if (e0 + k < W) out[k] = rec[k];
+            }
+        } else {
+            uint16_t* base = rp + (size_t)fc * 6 * H * WP + (size_t)y * WP + e0;   // e0 is a multiple of 4, WP of 8: 8-byte aligned
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (e0 + k + 1 < W) c1[k] = (uint16_t)st[s3][k + 1];
+            for (int s3 = 0; s3 < 3; s3++) {
+                uint16_t* c0 = base + (size_t)(2 * s3) * H * WP;       // copy 0: element i at index i       (i <= W-1)
+                uint16_t* c1 = base + (size_t)(2 * s3 + 1) * H * WP;   // copy 1: element i at index i - 1   (indices 0 .. W-2)
+                if (e0 + 3 < W) *reinterpret_cast<uint2*>(c0) = make_uint2(st[s3][0] | (st[s3][1] << 16), st[s3][2] | (st[s3][3] << 16));
+                else
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (e0 + k < W) c0[k] = (uint16_t)st[s3][k];
+                if (e0 + 4 < W) *reinterpret_cast<uint2*>(c1) = make_uint2(st[s3][1] | (st[s3][2] << 16), st[s3][3] | (st[s3][4] << 16));
+                else
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (e0 + k + 1 < W) c1[k] = (uint16_t)st[s3][k + 1];
+            }
         }
     }
 }
