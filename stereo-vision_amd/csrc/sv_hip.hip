@@ -71,7 +71,7 @@ struct sv_ctx {
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: one frame per workgroup pipeline
-    bool attr_sweep[2][8][2] = {}, attr_cost2[2][2][8] = {}, attr_lrcheck = false;
+    bool attr_sweep[2][8][2] = {}, attr_cost2[2][3][8] = {}, attr_lrcheck = false;
     int sweep_cw = 0;                  // compute waves per sweep workgroup: 15 (one workgroup per CU), 7 (two), 0 = chosen per launch (SV_SWEEP_CW)
     int n_cu = 256;
     // concurrent paths for small batches (run_paths_fanout)
@@ -310,13 +310,20 @@ int launch_cost2_n(sv_ctx* c, int nb) {
     const sv_params& p = c->prm;
     const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
     const int TX = NCOL - 2 * r, WP = svk::cost_plane_pitch(W);
+    if constexpr (NT == 512 && CN == 1 && N <= 4) {
+        // Large batches: 64-column tiles (1024 threads, one workgroup per CU) recompute the 2r halo columns of the
+        // BT costs for 58 instead of 26 output columns: 27.9 -> 27.2 ms per 1024 frames at C2.  Only where the
+        // tile fits the 160 KB of LDS (D <= 128 with blocks up to 7x7) and the launch has enough tiles to go round.
+        if (nb >= 8 && (size_t)(2 * 64 + (2 * r + 2) * (64 - 2 * r)) * (16 * N) * 4 <= 160 * 1024 && c->debug_mode != 4)
+            return launch_cost2_n<N, CN, 1024>(c, nb);
+    }
     const size_t lds = (size_t)(2 * NCOL + (2 * r + 2) * TX) * (16 * N) * 4;
     if (lds > 160 * 1024) {
         // D = 256 with an 11 x 11 block: the 12-row ring of a 32-column tile is 164 KB.  24 tile columns fit.
         if constexpr (NT == 512 && N == 8) return launch_cost2_n<N, CN, 384>(c, nb);
         return fail(c, SV_ERR_UNSUPPORTED, "cost kernel tile of %zu bytes exceeds the 160 KB of LDS", lds);
     }
-    bool* attr_set = c->attr_cost2[CN == 3][NT != 512];  // per context: the attribute is per device
+    bool* attr_set = c->attr_cost2[CN == 3][NT == 512 ? 0 : (NT == 384 ? 1 : 2)];  // per context: the attribute is per device
     if (lds > 48 * 1024 && !attr_set[N - 1]) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_cost2<N, NT, CN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024));
@@ -697,7 +704,11 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         // production path with the median on: one kernel for both, the checked map stays in LDS (a row of keys
         // and three checked rows: 10 bytes per column).  The debug variants keep the two kernels (and disp_lr).
         const size_t lds_fused = (size_t)W * 10;
-        const bool fused_tail = !(p.flags & SV_FLAG_NO_MEDIAN) && (c->debug_mode == 0 || c->debug_mode == 3) && lds_fused <= 64 * 1024;
+        // (a workgroup walks its 16 + 2 rows one after the other: only with two workgroups per CU or more in the
+        // launch; a single 640x480 frame is faster through the 480 + 1200 small workgroups of the two kernels)
+        const long tail_wgs = (long)((H + svk::LRM_ROWS - 1) / svk::LRM_ROWS) * nb;
+        const bool fused_tail = !(p.flags & SV_FLAG_NO_MEDIAN) && (c->debug_mode == 0 || c->debug_mode == 3) && lds_fused <= 64 * 1024 &&
+                                tail_wgs >= 2L * c->n_cu;
         if (fused_tail) {
             hipLaunchKernelGGL(svk::k_lr_median, dim3((H + svk::LRM_ROWS - 1) / svk::LRM_ROWS, nb), dim3(256), lds_fused, c->stream,
                                (const uint2*)c->rec.p, disp16, W, H, D, thr, (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
