@@ -70,3 +70,15 @@ def test_python_binding_has_no_cpu_fallback():
     csrc = os.path.join(ROOT, "stereo-vision_amd", "csrc")
     for f in os.listdir(csrc):
         assert "sv_ref" not in open(os.path.join(csrc, f), errors="ignore").read(), f
+
+
+@pytest.mark.skipif(_gpu_present(), reason="checks the no-device behaviour")
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py has no CPU path to fall back to: without a device it stops with a message, it does not time the oracle."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "no HIP device" in (r.stderr + r.stdout)
+    assert "frames/s" not in r.stdout
