@@ -166,12 +166,20 @@ def main():
     pairs = [synth.stereo_pair(seed0 + i, W, H, D) for i in range(n_distinct)]
     lefts = [p[0] for p in pairs]
     rights = [p[1] for p in pairs]
+    m = svhip.Matcher(W, H, params, device=local_rank)
+    while True:   # the volumes of the default batch take 140 of the 288 GB: on a card with less to give, halve it
+        try:
+            m.set_batch(B)
+            break
+        except svhip.SvError as e:
+            if B <= 64:
+                raise
+            sys.stderr.write("bench: batch %d does not fit (%s); trying %d\n" % (B, str(e)[:120], B // 2))
+            B //= 2
+    n_distinct = min(n_distinct, B)
     lt = torch.from_numpy(np.stack([lefts[i % n_distinct] for i in range(B)])).cuda()
     rt = torch.from_numpy(np.stack([rights[i % n_distinct] for i in range(B)])).cuda()
     out = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
-
-    m = svhip.Matcher(W, H, params, device=local_rank)
-    m.set_batch(B)
     stream = torch.cuda.current_stream()
     m.set_stream(stream.cuda_stream)
 

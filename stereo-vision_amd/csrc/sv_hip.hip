@@ -159,7 +159,13 @@ int check_params(sv_ctx* c, const sv_params* p, int W, int H) {
 int ensure(sv_ctx* c, Buf& b, size_t bytes) {
     if (b.n >= bytes && b.p) return SV_OK;
     if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.n = 0; }
-    HIPCHK(c, hipMalloc(&b.p, bytes));
+    const hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: the context stays usable (a smaller sv_set_batch may follow)
+        b.p = nullptr;
+        b.n = 0;
+        return fail(c, SV_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
     b.n = bytes;
     return SV_OK;
 }
