@@ -693,8 +693,10 @@ __device__ __forceinline__ void agg_body(const uint32_t* __restrict__ C, uint32_
 #pragma unroll
         for (int k = 0; k < N; k++) {
             // C + min(a, dd) - dd  ==  C - max(dd - a, 0): one saturating subtract
-            const uint32_t t = pk_min(pk_add(pk_min(m[k], m[k + 1]), P1P1), r[k]);
-            uint32_t L = pk_sub(c[k], pk_sub_sat(dd, t));
+            // plain 32-bit add / subtract where no half can carry or borrow (cheaper to issue than the packed
+            // forms): every L <= 32767 and sv_check_params keeps 32767 + P1 <= 65535; C >= P2 >= max(dd - t, 0)
+            const uint32_t t = pk_min(pk_min(m[k], m[k + 1]) + P1P1, r[k]);
+            uint32_t L = c[k] - pk_sub_sat(dd, t);
             r[k] = L;
             mn = pk_min(mn, L);
             snew[k] = FIRST ? L : pk_add_sat15(s[k], L);

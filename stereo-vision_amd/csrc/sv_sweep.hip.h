@@ -76,8 +76,10 @@ __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_
     uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const uint32_t t = pk_min(pk_add(pk_min(m[k], m[k + 1]), P1P1), r[k]);
-        L[k] = pk_sub(c[k], pk_sub_sat(dd, t));
+        // plain 32-bit add / subtract where no half can carry or borrow (cheaper to issue than the packed forms):
+        // every L <= 32767 and sv_check_params keeps 32767 + P1 <= 65535; C >= P2 >= max(dd - t, 0)
+        const uint32_t t = pk_min(pk_min(m[k], m[k + 1]) + P1P1, r[k]);
+        L[k] = c[k] - pk_sub_sat(dd, t);
         mn = pk_min(mn, L[k]);
     }
     mn_out = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // this lane's minimum in both halves; the row's: row16_min_1p3
