@@ -10,13 +10,19 @@ A "step" is one pass of the hot path (prefilter -> cost volume -> 8-path SGM -> 
 median; sv_compute_gray_batch_dev) over one batch of synthetic stereo pairs that are already
 resident in HBM.  value = frames of all ranks / max-over-ranks wall time of exactly K steps.
 
-roofline: the dominant kernel is the aggregation kernel: svk::k_sweep (four SGM paths of a sweep over
-the whole batch per launch; large batches, D <= 128) or svk::k_agg (one path per launch).  Its
-average launch duration is measured live with HIP events recorded by libsv_hip on the stream the
-kernels run on, over the K timed steps; achieved = algorithmic bytes per launch (3 * V * batch per
-path, V = (W-D)*H*D*2, SURVEY.md 8(d): 12 * V * batch for a four-path sweep) / that duration.  The
-fused sweep moves far fewer bytes than that (traffic = the PMC figure), so its algorithmic rate can
-exceed the HBM peak; hbm_actual_gbs = traffic / duration is what the memory system really carries.
+roofline: the dominant kernel is the aggregation launch that takes longest: with the fused sweeps (large
+batches, D <= 256) svk::k_sweep<N, true, CW>, the second sweep (paths L, UL, U, UR + winner-take-all); with
+per-path launches svk::k_agg.  Its launch duration is measured live with HIP events that libsv_hip records
+on the stream the kernels run on, after EVERY aggregation launch, over the K timed steps
+(sv_get_aggregation_timings).  achieved = ALGORITHMIC bytes of that launch / that duration, where the
+algorithmic bytes of a fused launch are what one pass must move: sweep 1 = 2 V per frame
+(C read, S written), sweep 2 = 2 V + 8 W H (C and S read, 8-byte WTA records written), cost = V + 2 W H,
+V = (W-D)*H*D*2; a per-path launch = 3 V.  traffic = HBM bytes of the same kernel from the
+committed rocprofv3 --pmc passes (profiles/r02_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, the gfx950
+correction of MI355X_MICROARCH.md), null when that file was taken from other kernel sources than the ones
+this run loads.  SURVEY 8(d)'s per-path model (3 V per path whatever the fusion) is reported beside it as
+per_path_model_gbs: a fused sweep moves a third of those bytes, so that figure exceeds the HBM peak and is
+no roofline fraction.
 
 cpu_baseline: the CPU oracle (oracle/libsv_ref.so, a restatement = "port"; OpenCV is not
 installed) timed single-threaded on rank 0 on a bounded sample of the same workload.
@@ -101,16 +107,34 @@ def cpu_baseline(W, H, D, paths, left, right, budget_s=10.0, threads=16):
     return out
 
 
-def pmc_traffic(config, batch, kernel):
-    """HBM bytes per aggregation launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this workload, gfx950 FETCH_SIZE x2 correction applied);
-    None when no pass was collected for this config/batch/kernel."""
+KERNEL_SOURCES = ("sv_hip.hip", "sv_kernels.hip.h", "sv_sweep.hip.h", "sv_blf.hip.h")
+
+
+def source_sha():
+    """sha256 over the kernel sources libsv_hip.so is built from: ties a committed PMC pass to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "stereo-vision_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(config, batch):
+    """{kernel name: HBM bytes per launch} from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this workload, gfx950 FETCH_SIZE x2 correction applied), the
+    file's name and the sources it belongs to; ({}, ...) when no pass exists for this config / batch or the pass
+    was taken from other kernel sources than the ones in the tree now."""
+    path = os.path.join("profiles", "r02_traffic.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f).get("%s_b%d%s" % (config, batch, "_sweep" if kernel == "svk::k_sweep" else ""))
-        return int(t["traffic_bytes_per_launch"]) if t else None
-    except (OSError, ValueError, KeyError):
-        return None
+        with open(os.path.join(ROOT, path)) as f:
+            t = json.load(f)
+        entry = t.get("%s_b%d" % (config, batch))
+        if not entry or t.get("source_sha") != source_sha():
+            return {}, path, t.get("source_sha")
+        return {k: int(v["traffic_bytes_per_launch"]) for k, v in entry["kernels"].items()}, path, t.get("source_sha")
+    except (OSError, ValueError, KeyError, TypeError):
+        return {}, path, None
 
 
 def main():
@@ -214,30 +238,55 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    m.synchronize()        # raises if a warm-up launch reported a device-side error
     m.enable_timing(True)  # HIP events on the kernels' stream, read back after the timed region
+    out.fill_(-32768)      # the timed steps must rewrite every pixel: nothing stale from the warm-up survives
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    # every rank, outside any try: a sweep that timed out (deferred device-side error) fails the run
+    m.synchronize()
     stage_ms = m.timings()
+    agg_ms = m.aggregation_timings()
     m.enable_timing(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # sanity: the timed output must be a plausible disparity map (not a skipped launch)
+    # The timed output must be the right answer, not just a plausible one (no oracle here: the oracle is the
+    # checker of tests/ and smoke()).  (1) every pixel was rewritten and most are valid; (2) the batch loops
+    # n_distinct pairs, so frame i must equal frame i mod n_distinct - frames that sit in different workgroup
+    # pipelines of the sweep; (3) the first frames must equal what the per-path kernels (another code path,
+    # pinned to the oracle by tests/) give for them.
+    n_launch, n_sweeps = m.last_aggregation()
+    if int((out == -32768).sum().item()) != 0:
+        raise SystemExit("bench: the timed steps left pixels unwritten")
     valid = float((out[:, :, D:] >= 0).float().mean().item())
     if not valid > 0.5:
         raise SystemExit("bench: output looks wrong (valid fraction %.3f)" % valid)
+    if B > n_distinct:
+        reps = B // n_distinct
+        same = bool((out[:reps * n_distinct].view(reps, n_distinct, H, W) == out[:n_distinct].unsqueeze(0)).all().item())
+        if not same:
+            raise SystemExit("bench: frames of the same pair differ across the batch")
+    if args.config != "c3" and n_sweeps > 0:
+        ncheck = min(4, B)
+        chk = torch.empty((ncheck, H, W), dtype=torch.int16, device="cuda")
+        m.set_debug(4)   # plain per-path launches
+        m.compute_gray_batch_dev(ncheck, lt, rt, chk)
+        m.synchronize()
+        m.set_debug(0)
+        if not bool((chk == out[:ncheck]).all().item()):
+            raise SystemExit("bench: fused sweeps and per-path kernels disagree")
 
     # what a plain copy kernel gets out of this GPU's HBM (report it beside the nominal peak)
     copy_gbs = None
     if rank == 0:
         try:
-            m.synchronize()
             a_, b_ = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"), torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(3):
@@ -257,14 +306,36 @@ def main():
         fps = frames / elapsed
         V = (W - D) * H * D * 2
         n_paths = bin(params.path_mask).count("1")
-        n_launch, n_sweeps = m.last_aggregation()
-        kernel = "svk::k_sweep" if n_sweeps == n_launch and n_sweeps > 0 else "svk::k_agg"
-        launch_s = stage_ms["aggregation"] * 1e-3 / n_launch          # mean duration of one aggregation launch
-        # algorithmic bytes: every path reads C and reads+writes S, all frames of the batch
-        agg_bytes_per_launch = 3 * V * B * n_paths // n_launch
-        achieved = agg_bytes_per_launch / launch_s / 1e9
-        traffic = pmc_traffic(args.config, B, kernel)
+        fused = n_sweeps == n_launch and n_sweeps > 0
+        cw = m.last_sweep_waves()
+        # per-launch algorithmic bytes and kernel names, in launch order
+        if fused:
+            names = ["svk::k_sweep<%d, false, %d>" % (D // 32, cw), "svk::k_sweep<%d, true, %d>" % (D // 32, cw)]
+            alg = [2 * V * B, (2 * V + 8 * W * H) * B]
+        else:
+            names = ["svk::k_agg"] * len(agg_ms)
+            alg = [3 * V * B] * len(agg_ms)
+        traffic_by_kernel, traffic_file, traffic_sha = pmc_traffic(args.config, B)
+        kstats = []
+        for nm, ms_, by in zip(names, agg_ms, alg):
+            tr = traffic_by_kernel.get(nm)
+            kstats.append({"kernel": nm, "launch_us": round(ms_ * 1e3, 2), "algorithmic_bytes": by,
+                           "achieved_gbs": round(by / (ms_ * 1e-3) / 1e9, 1), "frac": round(by / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": tr, "hbm_actual_gbs": round(tr / (ms_ * 1e-3) / 1e9, 1) if tr else None})
+        cost_name = "svk::k_cost2<%d, %d, 1>" % (D // 32, 1024 if (B >= 8 and D <= 128) else 512)
+        cost_bytes = (V + 2 * W * H) * B
+        cost_tr = traffic_by_kernel.get(cost_name)
+        kstats.append({"kernel": cost_name + " (+ k_cost_col0; stage time)", "launch_us": round(stage_ms["cost"] * 1e3, 2),
+                       "algorithmic_bytes": cost_bytes, "achieved_gbs": round(cost_bytes / (stage_ms["cost"] * 1e-3) / 1e9, 1),
+                       "frac": round(cost_bytes / (stage_ms["cost"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": cost_tr,
+                       "hbm_actual_gbs": round(cost_tr / (stage_ms["cost"] * 1e-3) / 1e9, 1) if cost_tr else None})
+        dom = max(kstats[:len(agg_ms)], key=lambda k: k["launch_us"])   # the dominant kernel: the longest aggregation launch
+        # whole frame: the bytes a fully fused pipeline must move (cost writes C; each sweep reads C; S written once and
+        # read once; records, planes) against SURVEY 8(d)'s per-path model
+        # (+ 60 bytes per pixel of images, BT statistics written and read, WTA records written and read, output)
+        fused_frame_bytes = 5 * V + 60 * W * H
         frame_bytes = m.algorithmic_bytes(4)
+        per_path_gbs = 3 * V * B * n_paths / (sum(agg_ms) * 1e-3) / 1e9
         res = {
             "metric": "disparity frames/sec per GPU at 640x480, D=128, 8 paths; % HBM roofline",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,16 +345,21 @@ def main():
                                     + (" inside the full pipeline: rectify remap x2 + gray x2 + SGM + vis + WLS x2 + depth" if args.config == "c3" else ""))
                                    % (args.config, W, H, D, paths),
                        "batch_per_gpu": B, "frames_per_step": world * B, "parallelism": "frame-sharded x%d" % world,
-                       "valid_fraction": round(valid, 4)},
+                       "valid_fraction": round(valid, 4),
+                       "checked": "all pixels rewritten; frame i == frame i mod %d over the batch; first frames == per-path kernels" % n_distinct},
             "per_gpu_fps": round(fps / world, 2),
-            "frame_roofline_frac": round(frame_bytes * (fps / world) / (HBM_PEAK_GBS * 1e9), 4),
+            "frame_fused_bytes_frac": round(fused_frame_bytes * (fps / world) / (HBM_PEAK_GBS * 1e9), 4),
+            "frame_per_path_model_x_peak": round(frame_bytes * (fps / world) / (HBM_PEAK_GBS * 1e9), 4),
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "launch_us": round(launch_s * 1e6, 2), "bytes_per_launch": agg_bytes_per_launch,
-                         "paths_per_launch": n_paths // n_launch,
-                         "hbm_actual_gbs": round(traffic / launch_s / 1e9, 1) if traffic else None,
-                         "hbm_copy_gbs": copy_gbs},
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_gbs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+                         "launch_us": dom["launch_us"], "bytes_per_launch": dom["algorithmic_bytes"],
+                         "hbm_actual_gbs": dom["hbm_actual_gbs"],
+                         "hbm_actual_frac": round(dom["hbm_actual_gbs"] / HBM_PEAK_GBS, 4) if dom["hbm_actual_gbs"] else None,
+                         "traffic_source": {"file": traffic_file, "kernel_sources_sha": traffic_sha, "this_run_sha": source_sha()},
+                         "limiter": "VALU issue (SQ counters, DESIGN.md section 4); the HBM fraction is what the north star asks for",
+                         "per_path_model_gbs": round(per_path_gbs, 1),
+                         "hbm_copy_gbs": copy_gbs, "kernels": kstats},
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, H, D, paths, lefts, rights)

@@ -268,6 +268,19 @@ int sv_disparity_vis_host(sv_ctx* ctx, const int16_t* disp16_host, uint8_t* vis_
  * matchSGBM, StereoMatcher.cpp:412) on a device disparity16 image, in place.  */
 int sv_filter_speckles_dev(sv_ctx* ctx, int16_t* disp16_dev, int max_size, int max_diff);
 
+/* The same filter for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  NO counterpart in the reference.  Same result as
+ * sv_filter_speckles_dev, bit for bit, but the union-find labels and component sizes live in a
+ * file-scope __device__ array of the library (2 ints per pixel for frames of up to
+ * SV_STATIC_MAX_PIXELS pixels = 16.7 MB per GPU, held until the process ends) instead of buffers the
+ * context allocates on first use: the call makes no hipMalloc / hipFree and no allocating library
+ * call.  Larger frames are rejected with SV_ERR_UNSUPPORTED.  Every call on one GPU shares that GPU's
+ * array (each call initialises what it uses), so two such calls that overlap in time on the same GPU
+ * - different contexts on different streams - race: serialise them.  Asynchronous on the context
+ * stream like the other *_dev entry points.                                                        */
+#define SV_STATIC_MAX_PIXELS (1920 * 1088)
+int sv_filter_speckles_static_dev(sv_ctx* ctx, int16_t* disp16_dev, int max_size, int max_diff);
+
 /* Replaces the two wls_filter->filter(...) calls of StereoMatcherNew::filterWLS
  * (StereoMatcher.cpp:154-160) on the filter made by
  * createDisparityWLSFilterGeneric(false) (StereoMatcher.cpp:265): outside the
@@ -383,10 +396,23 @@ int sv_debug_read_plane_host(sv_ctx* ctx, int which, int16_t* plane_host);
 int sv_enable_timing(sv_ctx* ctx, int enable);
 int sv_get_timings(sv_ctx* ctx, float* ms, int n);
 
+/* Duration in milliseconds of each kernel launch of the aggregation stage (stage 2 above), in launch
+ * order, from HIP events recorded on the context stream after every such launch: with the fused sweeps
+ * ms[0] = first sweep (paths R, DR, D, DL), ms[1] = second sweep (paths L, UL, U, UR + winner-take-all);
+ * with per-path kernels one entry per path.  Mean over the timed calls (the most recent 64 at most) that
+ * launched as many kernels as the last one; *n_launches = that number (at most 8); entries past it are 0.
+ * For bench.py's roofline line; no reference counterpart.                                        */
+int sv_get_aggregation_timings(sv_ctx* ctx, float* ms, int n, int* n_launches);
+
 /* How the last sv_compute_* call aggregated: kernel launches of the aggregation
  * stage, and how many of them were fused four-path sweeps (the rest are
  * single-path launches).  For profiling / bench.py; no reference counterpart. */
 int sv_last_aggregation(const sv_ctx* ctx, int* n_launches, int* n_fused_sweeps);
+
+/* Compute waves per workgroup (15 or 7; + one service wave) of the most recent fused-sweep launch, 0 if none
+ * ran yet: with num_disparities / 32 it names the kernel instance, svk::k_sweep<N, second, waves>, in a
+ * rocprofv3 trace.  For bench.py; no reference counterpart.                                       */
+int sv_last_sweep_waves(const sv_ctx* ctx);
 
 /* Algorithmic bytes per frame of the current geometry:
  * which: 0 cost, 1 aggregation, 2 wta, 3 tail, 4 frame.                       */

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -29,10 +30,36 @@ struct Buf {
 
 }  // namespace
 
+// Scratch of sv_filter_speckles_static_dev, the one entry point that allocates nothing: labels and
+// component sizes of the union-find speckle filter, one int each per pixel, for frames of up to
+// SV_STATIC_MAX_PIXELS pixels (16.7 MB; every GPU the library runs on holds its own copy until the
+// process ends).  In host code this name is only a handle for hipGetSymbolAddress: the address the
+// kernels get is g_scratch_dev[device], looked up once per device in sv_create with that device current.
+static __device__ __align__(256) int sv_static_scratch[2 * SV_STATIC_MAX_PIXELS];
+namespace {
+constexpr int MAX_DEVICES = 64;
+int* g_scratch_dev[MAX_DEVICES] = {};   // per device: device address of its copy of sv_static_scratch
+std::mutex g_scratch_mu;
+
+// called with `device` current
+hipError_t static_scratch_lookup(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_dev[device]) return hipSuccess;
+    int* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(sv_static_scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_dev[device] = ptr;
+    return hipSuccess;
+}
+}  // namespace
+
 struct sv_ctx {
     int device = 0;
     int W = 0, H = 0;
     int batch = 1;  // frames per launch the volume buffers are sized for
+    bool core_ok = false;  // the core buffers (statistics, C, S, records, planes) are allocated for `batch` frames
     sv_params prm{};
     hipStream_t stream = nullptr;
     char err[512] = {0};
@@ -78,6 +105,7 @@ struct sv_ctx {
     Buf Lbuf[8];
     int fanout_mode = 0;               // 0 auto, 1 always, -1 never
     int last_agg_launches = 0, last_agg_sweeps = 0;  // of the most recent compute call (sv_last_aggregation)
+    int last_sweep_cw = 0;             // compute waves per workgroup of the most recent sweep launch (sv_last_sweep_waves)
     int fuse_wta_min_batch = 6;  // batches below this run WTA as its own kernel (see run_sgm; crossover measured at 640x480 D=128)
     Buf disp_lr, out;        // i16 [H][W]
     Buf rgb_l, rgb_r;        // u8 [H][W][3] input staging
@@ -106,6 +134,8 @@ struct sv_ctx {
     static constexpr int EV_RING = 64, EV_PER = SV_N_TIMINGS;  // 6 marks per call
     bool timing = false;
     hipEvent_t ev[EV_RING][EV_PER] = {};
+    hipEvent_t ev_agg[EV_RING][8] = {};  // after each aggregation launch of the call (sv_get_aggregation_timings)
+    int ev_agg_n[EV_RING] = {};
     bool ev_ok = false;
     long ev_calls = 0;  // compute calls recorded since sv_enable_timing
 };
@@ -175,7 +205,16 @@ void release(Buf& b) {
     b.n = 0;
 }
 
-int alloc_core(sv_ctx* c) {
+// sizes of the core buffers for a batch of nb frames with the current parameters
+struct CoreSizes { size_t stat_l, stat_r, vol, rec, plane; };
+CoreSizes core_sizes(const sv_ctx* c, int nb) {
+    const size_t npx = (size_t)c->W * c->H * nb;
+    const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities * nb;
+    const size_t cn = (c->prm.flags & SV_FLAG_COST_RGB) ? 3 : 1;
+    return CoreSizes{npx * 8 * cn, (size_t)6 * c->H * svk::cost_plane_pitch(c->W) * 2 * nb * cn, nvol * 2, npx * 8, npx * 2};
+}
+
+int alloc_core_once(sv_ctx* c) {
     const size_t npx = (size_t)c->W * c->H * c->batch;
     const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities * c->batch;
     int rc;
@@ -189,6 +228,30 @@ int alloc_core(sv_ctx* c) {
     if ((rc = ensure(c, c->disp_lr, npx * 2))) return rc;
     if ((rc = ensure(c, c->out, npx * 2))) return rc;
     return SV_OK;
+}
+
+// (Re)allocates the core buffers for c->batch / c->prm.  ensure() frees a buffer before it asks for
+// the larger one (two 70 GB volumes cannot both be held twice), so a failed allocation leaves holes:
+// then every core buffer is released and the geometry the context had before (old_batch, old_prm:
+// buffers it did hold a moment ago) is allocated again.  If even that fails the context is left
+// with core_ok = false and every compute call is rejected with SV_ERR_NOMEM instead of launching
+// kernels on NULL volumes.
+int alloc_core(sv_ctx* c, int old_batch, const sv_params& old_prm) {
+    int rc = alloc_core_once(c);
+    if (rc == SV_OK) { c->core_ok = true; return SV_OK; }
+    char why[sizeof(c->err)];
+    snprintf(why, sizeof(why), "%s", c->err);
+    Buf* core[] = {&c->stat_l, &c->stat_r, &c->C, &c->S, &c->rec, &c->disp_lr, &c->out};
+    for (Buf* b : core) release(*b);
+    const int want_batch = c->batch;
+    c->batch = old_batch;
+    c->prm = old_prm;
+    c->core_ok = alloc_core_once(c) == SV_OK;
+    if (!c->core_ok)
+        for (Buf* b : core) release(*b);
+    fail(c, rc, "%s; batch %d not available, context %s", why, want_batch,
+         c->core_ok ? "keeps its previous batch size and parameters" : "has no volumes now: call sv_set_batch with a smaller size");
+    return rc;
 }
 
 // Strided host<->device image copy.  Dense rows (the usual case: cv::Mat::isContinuous) go through
@@ -489,7 +552,8 @@ int sweep_cw_for(const sv_ctx* c, int nb) {
     return cost(7, 1.063, 0.83) < cost(15, 1.0, 1.44) ? 7 : 15;
 }
 int launch_sweep(sv_ctx* c, bool second, int nb) {
-    return sweep_cw_for(c, nb) == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
+    c->last_sweep_cw = sweep_cw_for(c, nb);
+    return c->last_sweep_cw == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
 }
 // a sweep kernel gave up waiting for its neighbour band (never expected; reported at the next sync point)
 int check_sweep_error(sv_ctx* c) {
@@ -500,20 +564,26 @@ int check_sweep_error(sv_ctx* c) {
     return SV_OK;
 }
 
-int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff, int nb) {
-    const int n = c->W * c->H * nb;
-    int rc;
-    if ((rc = ensure(c, c->lab, (size_t)n * 4))) return rc;
-    if ((rc = ensure(c, c->cnt, (size_t)n * 4))) return rc;
-    const dim3 b(256), g1((n + 255) / 256), g2((c->W + 255) / 256, c->H, nb);
-    int* lab = (int*)c->lab.p;
-    int* cnt = (int*)c->cnt.p;
-    hipLaunchKernelGGL(svk::k_speckle_init, g1, b, 0, c->stream, img, lab, cnt, n);
-    hipLaunchKernelGGL(svk::k_speckle_merge, g2, b, 0, c->stream, img, lab, c->W, c->H, SV_INVALID_DISP_SCALED, max_diff);
-    hipLaunchKernelGGL(svk::k_speckle_count, dim3((n + 1023) / 1024), dim3(1024), 0, c->stream, img, lab, cnt, n, SV_INVALID_DISP_SCALED);
-    hipLaunchKernelGGL(svk::k_speckle_apply, g1, b, 0, c->stream, img, lab, cnt, n, SV_INVALID_DISP_SCALED, max_size);
+// cv::filterSpeckles on nb dense-packed frames, in place.  lab / cnt: one int per pixel each (labels are
+// pixel indices within the frame, so a frame must stay below 2^31 pixels; frames are a grid dimension).
+int speckle_launch(sv_ctx* c, int16_t* img, int* lab, int* cnt, int W, int H, int max_size, int max_diff, int nb, hipStream_t st) {
+    if ((size_t)W * H >= ((size_t)1 << 31)) return fail(c, SV_ERR_UNSUPPORTED, "speckle filter: frame of %dx%d pixels exceeds 2^31 labels", W, H);
+    if (nb < 1 || nb > 65535) return fail(c, SV_ERR_INVALID_ARG, "speckle filter: %d frames per call (1..65535)", nb);
+    const int n = W * H;
+    const dim3 b(256), g1((n + 255) / 256, nb), g2((W + 255) / 256, H, nb);
+    hipLaunchKernelGGL(svk::k_speckle_init, g1, b, 0, st, lab, cnt, n);
+    hipLaunchKernelGGL(svk::k_speckle_merge, g2, b, 0, st, img, lab, W, H, SV_INVALID_DISP_SCALED, max_diff);
+    hipLaunchKernelGGL(svk::k_speckle_count, dim3((n + 1023) / 1024, nb), dim3(1024), 0, st, img, lab, cnt, n, SV_INVALID_DISP_SCALED);
+    hipLaunchKernelGGL(svk::k_speckle_apply, g1, b, 0, st, img, lab, cnt, n, SV_INVALID_DISP_SCALED, max_size);
     HIPCHK(c, hipGetLastError());
     return SV_OK;
+}
+int speckle_dev(sv_ctx* c, int16_t* img, int max_size, int max_diff, int nb) {
+    const size_t n = (size_t)c->W * c->H * nb;
+    int rc;
+    if ((rc = ensure(c, c->lab, n * 4))) return rc;
+    if ((rc = ensure(c, c->cnt, n * 4))) return rc;
+    return speckle_launch(c, img, (int*)c->lab.p, (int*)c->cnt.p, c->W, c->H, max_size, max_diff, nb, c->stream);
 }
 
 int inv3(const double* m, double* o) {
@@ -613,10 +683,19 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     const int cn = (p.flags & SV_FLAG_COST_RGB) ? 3 : 1;
     if ((cn == 3) != rgb)
         return fail(c, SV_ERR_INVALID_ARG, "SV_FLAG_COST_RGB needs the RGB entry points (sv_compute_rgb_*), and only those accept it");
+    {   // never launch on a missing or short volume (a failed sv_set_batch / sv_set_params leaves core_ok = false)
+        const CoreSizes z = core_sizes(c, nb);
+        if (!c->core_ok || nb > c->batch || !c->stat_l.p || !c->stat_r.p || !c->C.p || !c->S.p || !c->rec.p || !c->disp_lr.p || !c->out.p ||
+            c->stat_l.n < z.stat_l || c->stat_r.n < z.stat_r || c->C.n < z.vol || c->S.n < z.vol || c->rec.n < z.rec || c->disp_lr.n < z.plane)
+            return fail(c, SV_ERR_NOMEM, "the context holds no volumes for %d frames (an earlier sv_set_batch / sv_set_params failed): call sv_set_batch again", nb);
+    }
     const bool tm = c->timing && c->ev_ok;
     int e = 0;
     hipEvent_t* evs = c->ev[c->ev_calls % sv_ctx::EV_RING];
     auto mark = [&]() { if (tm) (void)hipEventRecord(evs[e++], c->stream); };
+    int n_agg_ev = 0;
+    hipEvent_t* evs_agg = c->ev_agg[c->ev_calls % sv_ctx::EV_RING];
+    auto agg_mark = [&]() { if (tm && n_agg_ev < 8) (void)hipEventRecord(evs_agg[n_agg_ev++], c->stream); };
     // Fusing WTA into the last path saves one volume write + read but triples that launch's
     // instruction count per step; with few frames in flight the path kernels are latency-bound
     // (one wave per SIMD or less), so the fusion only pays once the batch fills the chip.
@@ -665,6 +744,7 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
             rest &= ~0x0Fu;
             first = false;
             c->last_agg_launches++; c->last_agg_sweeps++;
+            agg_mark();
         }
         if (sw2) {
             int rc = launch_sweep(c, true, nb);
@@ -672,6 +752,7 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
             rest = 0;
             wta_done = true;
             c->last_agg_launches++; c->last_agg_sweeps++;
+            agg_mark();
         }
         // few frames: all remaining paths at once, each into its own volume, then sum + WTA
         const int n_rest = __builtin_popcount(rest);
@@ -683,6 +764,7 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
             if (rc) return rc;
             rest = 0;
             wta_done = true;
+            agg_mark();
         }
         if (rest) {
             int last = 7;
@@ -692,6 +774,7 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
                     const bool fl = dir == last && fuse;
                     launch_agg(c, dir, (first ? 1 : 0) | (fl ? 2 : 0), nb);
                     c->last_agg_launches++;
+                    agg_mark();
                     first = false;
                     wta_done = wta_done || fl;
                 }
@@ -740,7 +823,10 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     }
     mark();
     HIPCHK(c, hipGetLastError());
-    if (tm) c->ev_calls++;
+    if (tm) {
+        c->ev_agg_n[c->ev_calls % sv_ctx::EV_RING] = n_agg_ev;
+        c->ev_calls++;
+    }
     return SV_OK;
 }
 
@@ -795,6 +881,8 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
         return fail(c, SV_ERR_NO_DEVICE, "device %d is %s; libsv_hip is built for gfx950 only", device, prop.gcnArchName);
     for (int r = 0; r < sv_ctx::EV_RING; r++)
         for (int i = 0; i < sv_ctx::EV_PER; i++) HIPCHK(c, hipEventCreate(&c->ev[r][i]));
+    for (int r = 0; r < sv_ctx::EV_RING; r++)
+        for (int i = 0; i < 8; i++) HIPCHK(c, hipEventCreate(&c->ev_agg[r][i]));
     c->ev_ok = true;
     if (const char* e = getenv("SV_FUSE_WTA_MIN_BATCH")) c->fuse_wta_min_batch = atoi(e);  // tuning knobs
     if (const char* e = getenv("SV_SWEEP_MIN_BATCH")) c->sweep_min_batch = atoi(e);
@@ -804,7 +892,8 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     if (const char* e = getenv("SV_SWEEP_NCU")) c->n_cu = atoi(e) > 0 ? atoi(e) : c->n_cu;  // tests: few groups, many frames each
     HIPCHK(c, hipHostMalloc((void**)&c->sw_error, sizeof(unsigned int), hipHostMallocMapped));
     *c->sw_error = 0;
-    return alloc_core(c);
+    HIPCHK(c, static_scratch_lookup(device));  // this device's copy of the static scratch (sv_filter_speckles_static_dev)
+    return alloc_core(c, 1, c->prm);
 }
 
 int sv_destroy(sv_ctx* c) {
@@ -842,6 +931,9 @@ int sv_destroy(sv_ctx* c) {
                 for (int r = 0; r < sv_ctx::EV_RING; r++)
                     for (int i = 0; i < sv_ctx::EV_PER; i++)
                         if (c->ev[r][i]) (void)hipEventDestroy(c->ev[r][i]);
+            for (int r = 0; r < sv_ctx::EV_RING; r++)
+                for (int i = 0; i < 8; i++)
+                    if (c->ev_agg[r][i]) (void)hipEventDestroy(c->ev_agg[r][i]);
         }
     }
     delete c;
@@ -857,8 +949,9 @@ int sv_set_params(sv_ctx* c, const sv_params* params) {
     const bool regeom = params->num_disparities != c->prm.num_disparities ||
                         ((params->flags ^ c->prm.flags) & SV_FLAG_COST_RGB);  // statistics per colour plane
     if (regeom) HIPCHK(c, hipStreamSynchronize(c->stream));
+    const sv_params old = c->prm;
     c->prm = *params;
-    return regeom ? alloc_core(c) : SV_OK;
+    return regeom ? alloc_core(c, c->batch, old) : SV_OK;
 }
 
 int sv_get_params(const sv_ctx* c, sv_params* params) {
@@ -887,8 +980,9 @@ int sv_set_batch(sv_ctx* c, int max_frames) {
     DevGuard g(c->device);
     if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     if (max_frames != c->batch) HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int old = c->batch;
     c->batch = max_frames;
-    return alloc_core(c);
+    return alloc_core(c, old, c->prm);
 }
 
 int sv_compute_gray_batch_dev(sv_ctx* c, int n_frames, const uint8_t* left_dev, const uint8_t* right_dev,
@@ -1282,6 +1376,21 @@ int sv_filter_speckles_dev(sv_ctx* c, int16_t* d16, int max_size, int max_diff) 
     return speckle_dev(c, d16, max_size, max_diff, 1);
 }
 
+int sv_filter_speckles_static_dev(sv_ctx* c, int16_t* d16, int max_size, int max_diff) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!d16 || max_size < 0 || max_diff < 0) return fail(c, SV_ERR_INVALID_ARG, "bad speckle argument");
+    const size_t npx = (size_t)c->W * c->H;
+    if (npx > (size_t)SV_STATIC_MAX_PIXELS)
+        return fail(c, SV_ERR_UNSUPPORTED, "sv_filter_speckles_static_dev: %dx%d = %zu pixels exceed the static scratch of %d pixels; use sv_filter_speckles_dev",
+                    c->W, c->H, npx, SV_STATIC_MAX_PIXELS);
+    if (c->device < 0 || c->device >= MAX_DEVICES || !g_scratch_dev[c->device])
+        return fail(c, SV_ERR_HIP, "no static scratch address for device %d", c->device);
+    DevGuard g(c->device);
+    if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
+    int* const lab = g_scratch_dev[c->device];   // never the symbol's name: that is not a device address in host code
+    return speckle_launch(c, d16, lab, lab + SV_STATIC_MAX_PIXELS, c->W, c->H, max_size, max_diff, 1, c->stream);
+}
+
 int sv_depth_dev(sv_ctx* c, const int16_t* d16, const float* mapper, const double* Q, const double* R, float* depth) {
     return sv_depth_batch_dev(c, 1, d16, mapper, Q, R, depth);
 }
@@ -1612,6 +1721,8 @@ int sv_last_aggregation(const sv_ctx* c, int* n_launches, int* n_fused_sweeps) {
     return SV_OK;
 }
 
+int sv_last_sweep_waves(const sv_ctx* c) { return c ? c->last_sweep_cw : SV_ERR_INVALID_ARG; }
+
 int sv_synchronize(sv_ctx* c) {
     if (!c) return SV_ERR_INVALID_ARG;
     DevGuard g(c->device);
@@ -1697,6 +1808,32 @@ int sv_get_timings(sv_ctx* c, float* ms, int n) {
         acc[5] += t;
     }
     for (int i = 0; i < SV_N_TIMINGS; i++) ms[i] = (float)(acc[i] / (double)nset);
+    return SV_OK;
+}
+
+int sv_get_aggregation_timings(sv_ctx* c, float* ms, int n, int* n_launches) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    if (!ms || !n_launches || n < 1) return fail(c, SV_ERR_INVALID_ARG, "bad argument");
+    if (c->ev_calls <= 0) return fail(c, SV_ERR_INVALID_ARG, "no timed call yet (sv_enable_timing, then compute)");
+    DevGuard g(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // launches of the most recent call; the mean runs over the calls in the ring that launched the same number
+    const int nl = c->ev_agg_n[(c->ev_calls - 1) % sv_ctx::EV_RING];
+    *n_launches = nl;
+    const long nset = c->ev_calls < sv_ctx::EV_RING ? c->ev_calls : sv_ctx::EV_RING;
+    double acc[8] = {0};
+    long used = 0;
+    for (long k = 0; k < nset; k++) {
+        const long slot = (c->ev_calls - 1 - k) % sv_ctx::EV_RING;
+        if (c->ev_agg_n[slot] != nl) continue;
+        used++;
+        for (int i = 0; i < nl; i++) {
+            float t;
+            HIPCHK(c, hipEventElapsedTime(&t, i == 0 ? c->ev[slot][2] : c->ev_agg[slot][i - 1], c->ev_agg[slot][i]));
+            acc[i] += t;
+        }
+    }
+    for (int i = 0; i < n; i++) ms[i] = i < nl && used ? (float)(acc[i] / (double)used) : 0.0f;
     return SV_OK;
 }
 

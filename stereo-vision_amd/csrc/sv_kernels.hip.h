@@ -997,16 +997,23 @@ __device__ __forceinline__ void uf_union(int* __restrict__ lab, int a, int b) {
         b = old;
     }
 }
-__global__ __launch_bounds__(256) void k_speckle_init(const int16_t* __restrict__ img, int* __restrict__ lab,
-                                                       int* __restrict__ cnt, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { lab[i] = i; cnt[i] = 0; }
+// Frames of a batch are a grid dimension (blockIdx.y, or .z for the 2-D merge kernel); n = pixels per
+// frame, labels are pixel indices within the frame.
+__global__ __launch_bounds__(256) void k_speckle_init(int* __restrict__ lab, int* __restrict__ cnt, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t fo = (size_t)blockIdx.y * n;
+    lab[fo + i] = i;
+    cnt[fo + i] = 0;
 }
 __global__ __launch_bounds__(256) void k_speckle_merge(const int16_t* __restrict__ img, int* __restrict__ lab, int W, int H,
                                                         int new_val, int max_diff) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
-    int i = (blockIdx.z * H + y) * W + x, v = img[i];
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    img += fo;
+    lab += fo;
+    int i = y * W + x, v = img[i];
     if (v == new_val) return;
     if (x + 1 < W) { int u = img[i + 1]; if (u != new_val && abs(u - v) <= max_diff) uf_union(lab, i, i + 1); }
     if (y + 1 < H) { int u = img[i + W]; if (u != new_val && abs(u - v) <= max_diff) uf_union(lab, i, i + W); }
@@ -1021,6 +1028,10 @@ __global__ __launch_bounds__(1024) void k_speckle_count(const int16_t* __restric
     __shared__ int e_root[MAXE], e_cnt[MAXE], e_n;
     if (threadIdx.x == 0) e_n = 0;
     __syncthreads();
+    const size_t fo = (size_t)blockIdx.y * n;
+    img += fo;
+    lab += fo;
+    cnt += fo;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n && img[i] != new_val;
     int r = -1;
@@ -1054,11 +1065,13 @@ __global__ __launch_bounds__(1024) void k_speckle_count(const int16_t* __restric
 }
 __global__ __launch_bounds__(256) void k_speckle_apply(int16_t* __restrict__ img, const int* __restrict__ lab,
                                                         const int* __restrict__ cnt, int n, int new_val, int max_size) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || img[i] == new_val) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t fo = (size_t)blockIdx.y * n;
+    if (i >= n || img[fo + i] == new_val) return;
+    lab += fo;
     int r = lab[i];
     while (lab[r] != r) r = lab[r];
-    if (cnt[r] <= max_size) img[i] = (int16_t)new_val;
+    if (cnt[fo + r] <= max_size) img[fo + i] = (int16_t)new_val;
 }
 
 // ---------------------------------------------------------------------------------------------

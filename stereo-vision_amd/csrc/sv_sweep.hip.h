@@ -19,6 +19,14 @@
 // side: MI355X_MICROARCH.md "Valid forms", first row of the table).  Bands of one frame therefore
 // run as a pipeline, 2*60 steps apart, and a workgroup streams its band of frame after frame
 // without draining, so the 2-steps-per-row skew is paid once per launch, not once per frame.
+// Dispatch order: band b waits for band b-1 of its group, which has the next lower blockIdx.  The launch
+// may hold more workgroups than the chip has slots (n_groups * n_bands > resident capacity: after the
+// frames-per-group clamp, with SV_SWEEP_NCU, or when fewer workgroups fit a CU than the host assumed); that
+// is safe as long as workgroups START in blockIdx order, which the hardware dispatcher does for a 1-D grid
+// (observed, not an architectural promise; tests/test_gpu_sweep.py::test_sweep_grid_exceeds_residency
+// runs a grid of four times the capacity).  Every wait is bounded in time (SW_WAIT_TICKS); a timeout sets
+// the host-visible error word, publishes the band as finished so that the launch drains, and
+// sv_synchronize / the *_host entry points report it.
 // The second sweep is the same kernel on coordinates mirrored in x and y; its finished S stays in
 // registers and goes straight into winner-take-all.
 #pragma once
@@ -29,7 +37,11 @@ namespace svk {
 constexpr int SW_RING = 16;   // pixels in the import / export rings
 constexpr int SW_LEAD = 32;   // loop steps before stream pixel 0 (service pipeline warm-up), multiple of 4
 constexpr int SW_DEPTH = 4;   // global-load pipeline depth in steps
-constexpr int SW_SPIN_MAX = 1 << 18;
+// Bound of every wait on a neighbouring band, in ticks of the constant 100 MHz counter (s_memrealtime): 2 s of
+// time actually spent polling.  One poll interval counts for at most SW_WAIT_TICK_CAP ticks, so a pause of the
+// whole queue (another process's kernels time-sliced onto the GPU) does not run the bound out.
+constexpr unsigned long long SW_WAIT_TICKS = 200000000ull;
+constexpr unsigned long long SW_WAIT_TICK_CAP = 1000ull;
 
 struct SweepArgs {
     const uint32_t* C;             // [n_frames][H][W1][D/2] packed u16 pairs
@@ -311,10 +323,13 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 if (do_import) {
                     if ((t & 15) == 0 && t + 23 > 0) {
                         const unsigned need = (unsigned)min(t + 23, total_px);
-                        int spins = 0;
+                        unsigned long long waited = 0, last = __builtin_amdgcn_s_memrealtime();
                         while (__hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                             __builtin_amdgcn_s_sleep(16);
-                            if (++spins > SW_SPIN_MAX) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                            waited += min(now - last, SW_WAIT_TICK_CAP);
+                            last = now;
+                            if (waited > SW_WAIT_TICKS) {
                                 (*abortp) = 1;
                                 if (lane == 0) __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 break;
@@ -355,7 +370,10 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
             }
         }
         SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
-        if (do_export && !aborted) {
+        // Also after a timeout (the error word is set, the call's results are invalid anyway): the bands
+        // below must not each wait out their own bound on a counter that will never move.
+        (void)aborted;
+        if (do_export) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(flag_out, (unsigned)total_px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

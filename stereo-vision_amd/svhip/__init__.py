@@ -33,7 +33,8 @@ EXPORTS = (
     "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_filter_blf_joint_dev", "sv_filter_blf_joint_host", "sv_compute_rgb_batch_dev", "sv_disparity_vis_batch_dev", "sv_depth_batch_dev", "sv_world_image_dev", "sv_world_image_host",
     "sv_synchronize", "sv_last_aggregation", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
-    "sv_algorithmic_bytes", "sv_last_error", "sv_version")
+    "sv_algorithmic_bytes", "sv_last_error", "sv_version", "sv_get_aggregation_timings", "sv_filter_speckles_static_dev", "sv_last_sweep_waves")
+STATIC_MAX_PIXELS = 1920 * 1088   # SV_STATIC_MAX_PIXELS
 
 
 class Params(C.Structure):
@@ -128,6 +129,9 @@ def load():
     L.sv_debug_read_plane_host.argtypes = [vp, i32, vp]
     L.sv_enable_timing.argtypes = [vp, i32]
     L.sv_get_timings.argtypes = [vp, C.POINTER(C.c_float), i32]
+    L.sv_get_aggregation_timings.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]
+    L.sv_filter_speckles_static_dev.argtypes = [vp, vp, i32, i32]
+    L.sv_last_sweep_waves.argtypes = [vp]
     L.sv_algorithmic_bytes.restype = C.c_int64
     L.sv_algorithmic_bytes.argtypes = [vp, i32]
     _lib = L
@@ -193,6 +197,13 @@ class Matcher:
         ms = (C.c_float * N_TIMINGS)()
         self._chk(self._L.sv_get_timings(self._h, ms, N_TIMINGS))
         return dict(zip(TIMING_NAMES, list(ms)))
+
+    def aggregation_timings(self):
+        """ms of each kernel launch of the aggregation stage, in launch order (mean over the timed calls)."""
+        ms = (C.c_float * 8)()
+        n = C.c_int()
+        self._chk(self._L.sv_get_aggregation_timings(self._h, ms, 8, C.byref(n)))
+        return list(ms)[:n.value]
 
     def algorithmic_bytes(self, which=4):
         return int(self._L.sv_algorithmic_bytes(self._h, which))
@@ -388,6 +399,9 @@ class Matcher:
         self._chk(self._L.sv_last_aggregation(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_sweep_waves(self):
+        return int(self._L.sv_last_sweep_waves(self._h))
+
     def synchronize(self):
         self._chk(self._L.sv_synchronize(self._h))
 
@@ -421,6 +435,10 @@ class Matcher:
 
     def filter_speckles_dev(self, disp_t, max_size, max_diff):
         self._chk(self._L.sv_filter_speckles_dev(self._h, C.c_void_p(disp_t.data_ptr()), max_size, max_diff))
+
+    def filter_speckles_static_dev(self, disp_t, max_size, max_diff):
+        """The allocation-free variant (static device scratch, frames up to STATIC_MAX_PIXELS pixels)."""
+        self._chk(self._L.sv_filter_speckles_static_dev(self._h, C.c_void_p(disp_t.data_ptr()), max_size, max_diff))
 
     def remap_rgb_dev(self, which, src_t, dst_t):
         self._chk(self._L.sv_remap_rgb_dev(self._h, which, C.c_void_p(src_t.data_ptr()), C.c_void_p(dst_t.data_ptr())))

@@ -81,3 +81,42 @@ def test_parameter_pushes_and_batch_resizing(gpu):
         m.synchronize()
         assert all(np.array_equal(out[i].cpu().numpy(), ref) for i in range(nb)), nb
     m.close()
+
+
+def test_failed_set_batch_leaves_a_usable_context(gpu):
+    """a sv_set_batch that runs out of memory must not leave NULL volumes behind a batch
+    size that passes the checks: the context keeps its previous batch, computes correctly with it, and
+    a call with more frames is rejected with an error code (never a launch on a missing volume)."""
+    import torch
+    W, H, D = 640, 480, 128
+    hogs = []
+    try:
+        # take HBM until a 1024-pair context (140 GB) cannot fit any more
+        for _ in range(3):
+            h = svhip.Matcher(W, H, svhip.default_params(D, 8))
+            try:
+                h.set_batch(900)
+            except svhip.SvError:
+                h.close()
+                break
+            hogs.append(h)
+        m = svhip.Matcher(W, H, svhip.default_params(D, 8))
+        m.set_batch(4)
+        with pytest.raises(svhip.SvError) as e:
+            m.set_batch(1024)
+        assert e.value.code == -6, e.value
+        l, r, _ = synth.stereo_pair(202, W, H, D)
+        ref = svhip.Matcher(W, H, svhip.default_params(D, 8)).compute_gray(l, r)
+        lt = torch.from_numpy(np.stack([l] * 8)).cuda()
+        rt = torch.from_numpy(np.stack([r] * 8)).cuda()
+        out = torch.empty((8, H, W), dtype=torch.int16, device="cuda")
+        m.set_stream(torch.cuda.current_stream().cuda_stream)
+        m.compute_gray_batch_dev(4, lt, rt, out)     # right after the failed call: the previous batch still works
+        m.synchronize()
+        assert np.array_equal(out[:4].cpu().numpy(), np.stack([ref] * 4))
+        with pytest.raises(svhip.SvError):
+            m.compute_gray_batch_dev(8, lt, rt, out)  # more than the batch it kept: an error, not a fault
+        m.close()
+    finally:
+        for h in hogs:
+            h.close()

@@ -101,3 +101,133 @@ def test_fused_sweeps_d256_batch(gpu):
         for k in range(i, nb, 3):
             assert np.array_equal(got[k], ref), "frame %d differs" % k
     m.close()
+
+
+def _oracle_many(pairs, po, workers=8):
+    """svref.sgbm on many pairs, frame-parallel (ctypes releases the GIL inside the C oracle)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(lambda p: svref.sgbm(p[0], p[1], po), pairs))
+
+
+def _matcher_with_env(W, H, ph, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return svhip.Matcher(W, H, ph)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("cw", [15, 7])
+def test_sweep_grid_exceeds_residency(gpu, cw):
+    """band b waits for band b-1 (the next lower blockIdx) through HBM.  With SV_SWEEP_NCU = 1024
+    the launch holds four times as many workgroups as the chip has slots for them, so most bands start only
+    when earlier workgroups have left: still bit-exact against the per-path kernels and the oracle, no timeout."""
+    import torch
+    W, H, D, nb, nd = 160, 100, 64, 512, 16
+    ph, po = _params(D, 8)
+    pairs = [synth.stereo_pair(1300 + i, W, H, D) for i in range(nd)]
+    lt = torch.from_numpy(np.stack([pairs[i % nd][0] for i in range(nb)])).cuda()
+    rt = torch.from_numpy(np.stack([pairs[i % nd][1] for i in range(nb)])).cuda()
+    out = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+    m = _matcher_with_env(W, H, ph, SV_SWEEP_NCU=1024, SV_SWEEP_CW=cw)
+    m.set_batch(nb)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    m.synchronize()   # reports a hand-off timeout
+    assert m.last_aggregation() == (2, 2), "the fused sweeps should have run"
+    got = out.cpu().numpy()
+    refs = _oracle_many(pairs, po)
+    for i in range(nb):
+        assert np.array_equal(got[i], refs[i % nd]), "frame %d differs" % i
+    m.close()
+
+
+def test_sweep_bench_shape_every_frame(gpu):
+    """The shape bench.py streams (640x480 D=128, 16-wave workgroups, 32 frames per group) on two groups with 64
+    distinct pairs, EVERY output frame against the oracle."""
+    import torch
+    W, H, D, nb = 640, 480, 128, 64
+    ph, po = _params(D, 8)
+    pairs = [synth.stereo_pair(202 + i, W, H, D) for i in range(nb)]
+    lt = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    rt = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    out = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+    m = _matcher_with_env(W, H, ph, SV_SWEEP_NCU=16, SV_SWEEP_CW=15)   # 8 bands -> 2 groups of 32 frames
+    m.set_batch(nb)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    m.synchronize()
+    assert m.last_aggregation() == (2, 2)
+    got = out.cpu().numpy()
+    refs = _oracle_many(pairs, po, workers=16)
+    bad = [i for i in range(nb) if not np.array_equal(got[i], refs[i])]
+    assert not bad, "frames %s differ from the oracle" % bad
+    m.close()
+
+
+def test_sweep_frames_per_group_clamp(gpu):
+    """A group's block of C must stay below 2^34 bytes (32-bit dword offsets in the kernel): at 1920x1080 D=256
+    that is 17 frames.  20 frames on ONE workgroup pipeline trip the clamp (two groups of 17 and 3 frames, more
+    workgroups than SV_SWEEP_NCU asked for): every frame against the per-path kernels, one against the oracle."""
+    import torch
+    W, H, D, nb = 1920, 1080, 256, 20
+    ph, po = _params(D, 8)
+    pairs = [synth.stereo_pair(404 + i, W, H, D) for i in range(2)]
+    lt = torch.from_numpy(np.stack([pairs[i % 2][0] for i in range(nb)])).cuda()
+    rt = torch.from_numpy(np.stack([pairs[i % 2][1] for i in range(nb)])).cuda()
+    out = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+    m = _matcher_with_env(W, H, ph, SV_SWEEP_NCU=20)   # 39 bands of 28 rows, two workgroups per CU -> one pipeline
+    m.set_batch(nb)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.set_debug(3)
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    m.synchronize()
+    assert m.last_aggregation() == (2, 2)
+    got = out.cpu().numpy()
+    m.set_debug(4)   # plain per-path launches
+    out2 = torch.empty((2, H, W), dtype=torch.int16, device="cuda")
+    m.compute_gray_batch_dev(2, lt, rt, out2)
+    m.synchronize()
+    exp = out2.cpu().numpy()
+    assert np.array_equal(exp[0], svref.sgbm(pairs[0][0], pairs[0][1], po))
+    for i in range(nb):
+        assert np.array_equal(got[i], exp[i % 2]), "frame %d differs" % i
+    m.close()
+
+
+def test_two_contexts_sweep_concurrently(gpu):
+    """Two contexts on two streams, both in the fused-sweep path at the same time (each launch alone would fill
+    the chip): their band hand-offs and progress counters are per context, results bit-exact."""
+    import torch
+    W, H, D, nb, nd = 320, 240, 64, 64, 8
+    ph, po = _params(D, 8)
+    sets = []
+    for k in range(2):
+        pairs = [synth.stereo_pair(1500 + 10 * k + i, W, H, D) for i in range(nd)]
+        st = torch.cuda.Stream()
+        m = svhip.Matcher(W, H, ph)
+        m.set_batch(nb)
+        m.set_debug(3)
+        m.set_stream(st.cuda_stream)
+        lt = torch.from_numpy(np.stack([pairs[i % nd][0] for i in range(nb)])).cuda()
+        rt = torch.from_numpy(np.stack([pairs[i % nd][1] for i in range(nb)])).cuda()
+        out = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+        sets.append((m, st, pairs, lt, rt, out))
+    torch.cuda.synchronize()
+    for _ in range(3):   # several rounds so that the launches of the two streams really overlap
+        for m, st, pairs, lt, rt, out in sets:
+            m.compute_gray_batch_dev(nb, lt, rt, out)
+    for m, st, pairs, lt, rt, out in sets:
+        m.synchronize()
+        assert m.last_aggregation() == (2, 2)
+        got = out.cpu().numpy()
+        refs = _oracle_many(pairs, po)
+        for i in range(nb):
+            assert np.array_equal(got[i], refs[i % nd]), "frame %d differs" % i
+        m.close()
