@@ -256,6 +256,12 @@ int sv_remap_rgb_dev(sv_ctx* ctx, int which, const uint8_t* src_rgb_dev, uint8_t
 int sv_compute_rgb_host(sv_ctx* ctx, const uint8_t* left_rgb_host, size_t left_stride,
                         const uint8_t* right_rgb_host, size_t right_stride, int rectify,
                         int16_t* disp16_host, size_t disp_stride);
+/* The same plus the call that ends matchSGBMCUDA, getDisparityVis(disp16, vis, vis_scale)
+ * (StereoMatcher.cpp:437): the 8-bit image is made on the device from the map that is still there and
+ * comes back with it, one stream synchronisation for both.  vis_host may be NULL (= sv_compute_rgb_host). */
+int sv_compute_rgb_vis_host(sv_ctx* ctx, const uint8_t* left_rgb_host, size_t left_stride,
+                            const uint8_t* right_rgb_host, size_t right_stride, int rectify,
+                            int16_t* disp16_host, size_t disp_stride, uint8_t* vis_host, size_t vis_stride, int vis_scale);
 int sv_get_rectified_host(sv_ctx* ctx, int which, uint8_t* rgb_host, size_t stride);
 
 /* Replaces cv::ximgproc::getDisparityVis(disp16, vis, 3)

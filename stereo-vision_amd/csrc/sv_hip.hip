@@ -1291,12 +1291,12 @@ int sv_remap_rgb_dev(sv_ctx* c, int which, const uint8_t* src, uint8_t* dst) {
     return SV_OK;
 }
 
-int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int rectify,
-                        int16_t* disp16, size_t ds) {
+int sv_compute_rgb_vis_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int rectify,
+                            int16_t* disp16, size_t ds, uint8_t* vis, size_t vs, int vis_scale) {
     if (!c) return SV_ERR_INVALID_ARG;
     if (!left || !right || !disp16) return fail(c, SV_ERR_INVALID_ARG, "NULL image pointer");
     const size_t W = c->W, H = c->H;
-    if (ls < 3 * W || rs < 3 * W || ds < 2 * W) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
+    if (ls < 3 * W || rs < 3 * W || ds < 2 * W || (vis && vs < W)) return fail(c, SV_ERR_INVALID_ARG, "stride smaller than a row");
     if (rectify && !c->have_maps) return fail(c, SV_ERR_NO_MAPS, "rectification maps not uploaded (sv_upload_maps_host)");
     DevGuard g(c->device);
     if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
@@ -1306,6 +1306,7 @@ int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t
         if ((rc = ensure(c, *b, W * H * 3))) return rc;
     if ((rc = ensure(c, c->gray_l, W * H))) return rc;
     if ((rc = ensure(c, c->gray_r, W * H))) return rc;
+    if (vis && (rc = ensure(c, c->vis, W * H))) return rc;
     Buf& dl = rectify ? c->rgb_l : c->rect_l;
     Buf& dr = rectify ? c->rgb_r : c->rect_r;
     HIPCHK(c, copy2d(dl.p, 3 * W, left, ls, 3 * W, H, hipMemcpyHostToDevice, c->stream));
@@ -1324,8 +1325,17 @@ int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t
         if ((rc = run_sgm(c, (const uint8_t*)c->gray_l.p, (const uint8_t*)c->gray_r.p, (int16_t*)c->out.p))) return rc;
     }
     HIPCHK(c, copy2d(disp16, ds, c->out.p, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+    if (vis) {   // getDisparityVis(disp16, vis, scale) from the map that is still on the device
+        if ((rc = sv_disparity_vis_dev(c, (const int16_t*)c->out.p, (uint8_t*)c->vis.p, vis_scale))) return rc;
+        HIPCHK(c, copy2d(vis, vs, c->vis.p, W, W, H, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_sweep_error(c);
+}
+
+int sv_compute_rgb_host(sv_ctx* c, const uint8_t* left, size_t ls, const uint8_t* right, size_t rs, int rectify,
+                        int16_t* disp16, size_t ds) {
+    return sv_compute_rgb_vis_host(c, left, ls, right, rs, rectify, disp16, ds, nullptr, 0, 0);
 }
 
 int sv_get_rectified_host(sv_ctx* c, int which, uint8_t* rgb, size_t stride) {

@@ -53,7 +53,7 @@ void StereoMatcherNew::updateHIPParams() {
 }
 
 bool StereoMatcherNew::ensureContext(int w, int h) {
-    if (ctx && (w != ctx_w || h != ctx_h)) { sv_destroy(ctx); ctx = nullptr; maps_uploaded = false; }
+    if (ctx && (w != ctx_w || h != ctx_h)) { sv_destroy(ctx); ctx = nullptr; mapper_on_device = false; }
     if (!ctx) {
         last_rc = sv_create(&ctx, device, w, h, &hip_params);
         if (last_rc) {
@@ -68,8 +68,9 @@ bool StereoMatcherNew::ensureContext(int w, int h) {
 }
 
 void StereoMatcherNew::compute() {
-    // updateMappings()/rectifyImages() (StereoMatcher.cpp:62-63): the maps come from the caller;
-    // the two cv::remap calls (stereoCamera.cpp:573-574) run on the GPU inside matchSGBMHIP.
+    // StereoMatcher.cpp:57-79, unchanged but for the new case
+    this->stereo->updateMappings();
+    this->stereo->rectifyImages();
     switch (stereo_parameters.stereo_matching) {
         case SGBM_HIP: matchSGBMHIP(); break;
         default:
@@ -79,9 +80,15 @@ void StereoMatcherNew::compute() {
 }
 
 // The new SM_MATCHING_ALG case (README.md:60-118 recipe): ends with "this->disparity16 = result".
+// Variant A: like matchSGBMCUDA (StereoMatcher.cpp:420-440) it takes the pair that
+// rectifyImages() has rectified on the CPU, through the public getters; StereoCamera is untouched.
+// Variant B (StereoCamera patched, setRectifyOnDevice(true)): the raw pair goes up and the two
+// cv::initUndistortRectifyMap, the two cv::remap and the cv::undistortPoints of MapperL run on the GPU,
+// fed by the matrices cv::stereoRectify left in the camera.
 void StereoMatcherNew::matchSGBMHIP() {
-    const Image& L = stereo->getImLeft();
-    const Image& R = stereo->getImRight();
+    const bool on_device = stereo->getRectifyOnDevice();                                       // PATCH B
+    const Image& L = on_device ? stereo->getImLeft() : stereo->getLRectified();
+    const Image& R = on_device ? stereo->getImRight() : stereo->getRRectified();
     if (L.empty() || R.empty()) { std::cout << "Images are not set! set the images first!" << std::endl; return; }  // stereoCamera.cpp:554-557
     if (L.channels != 3 || L.elem != 1 || R.rows != L.rows || R.cols != L.cols || R.channels != 3) {
         std::cout << "[StereoMatcherNew] !! image type error" << std::endl;  // bova_sgm.cu:45-49 exits here
@@ -89,25 +96,20 @@ void StereoMatcherNew::matchSGBMHIP() {
         return;
     }
     if (!ensureContext(L.cols, L.rows)) return;
-    const bool rectify = stereo->hasMaps();
-    if (rectify && (stereo->cameraChanged || !maps_uploaded)) {
-        last_rc = sv_upload_maps_host(ctx, stereo->map11.ptr<float>(), stereo->map12.ptr<float>(), stereo->map21.ptr<float>(),
-                                      stereo->map22.ptr<float>());
+    if (on_device && (stereo->takeRectificationChanged() || !mapper_on_device)) {              // PATCH B
+        const Image &KL = stereo->getKleft(), &KR = stereo->getKright(), &DL = stereo->getDistCoeffLeft(), &DR = stereo->getDistCoeffRight();
+        const Image &RL = stereo->getRLrect(), &RR = stereo->getRRrect(), &PL = stereo->getPLrect(), &PR = stereo->getPRrect();
+        last_rc = sv_init_rectify_map(ctx, 0, KL.ptr<double>(), DL.ptr<double>(), (int)DL.total(), RL.ptr<double>(), PL.ptr<double>());
+        if (!last_rc) last_rc = sv_init_rectify_map(ctx, 1, KR.ptr<double>(), DR.ptr<double>(), (int)DR.total(), RR.ptr<double>(), PR.ptr<double>());
+        if (!last_rc) last_rc = sv_update_mapper(ctx, 0, KL.ptr<double>(), DL.ptr<double>(), (int)DL.total(), RL.ptr<double>(), PL.ptr<double>());
         if (last_rc) { std::cout << "[StereoMatcherNew] !! " << sv_last_error(ctx) << std::endl; return; }
-        maps_uploaded = true;
-        stereo->cameraChanged = false;  // stereoCamera.cpp:576
+        mapper_on_device = true;
     }
-    Image d16(L.rows, L.cols, 1, 2);
-    last_rc = sv_compute_rgb_host(ctx, L.ptr<uint8_t>(), L.step(), R.ptr<uint8_t>(), R.step(), rectify ? 1 : 0,
-                                  d16.ptr<int16_t>(), d16.step());
+    Image d16(L.rows, L.cols, 1, 2), vis(L.rows, L.cols, 1, 1);
+    // the pair, disparity16 and its getDisparityVis(.,.,3) image (StereoMatcher.cpp:437) in one call
+    last_rc = sv_compute_rgb_vis_host(ctx, L.ptr<uint8_t>(), L.step(), R.ptr<uint8_t>(), R.step(), on_device ? 1 : 0,
+                                      d16.ptr<int16_t>(), d16.step(), vis.ptr<uint8_t>(), vis.step(), 3);
     if (last_rc) { std::cout << "[StereoMatcherNew] !! sgbm_hip failed: " << sv_last_error(ctx) << std::endl; return; }
-    stereo->imgLeftRect = Image(L.rows, L.cols, 3, 1);
-    stereo->imgRightRect = Image(L.rows, L.cols, 3, 1);
-    sv_get_rectified_host(ctx, 0, stereo->imgLeftRect.ptr<uint8_t>(), stereo->imgLeftRect.step());
-    sv_get_rectified_host(ctx, 1, stereo->imgRightRect.ptr<uint8_t>(), stereo->imgRightRect.step());
-    Image vis(L.rows, L.cols, 1, 1);
-    last_rc = sv_disparity_vis_host(ctx, d16.ptr<int16_t>(), vis.ptr<uint8_t>(), 3);  // getDisparityVis(.,.,3), StereoMatcher.cpp:437
-    if (last_rc) { std::cout << "[StereoMatcherNew] !! " << sv_last_error(ctx) << std::endl; return; }
     this->disparity = vis;
     this->disparity16 = d16;
 }
@@ -215,17 +217,63 @@ void StereoMatcherNew::setAlgorithm(std::string name) {
 
 Image StereoMatcherNew::depthFromDisparity(const Image& d16) {
     Image depth(d16.rows, d16.cols, 1, 4);
-    const Image& mapper = stereo->getMapperL();
     if (!ctx || d16.empty()) return depth;
-    if (mapper.empty()) {  // DispModule.cpp:347-348: return disparity/16 unprojected
+    // variant B: MapperL is on the device already (sv_update_mapper); variant A: the one updateMappings() made
+    const Image& mapper = stereo->getMapperL();
+    const bool dev_mapper = stereo->getRectifyOnDevice() && mapper_on_device;
+    if (!dev_mapper && mapper.empty()) {  // DispModule.cpp:347-348: return disparity/16 unprojected
         for (int r = 0; r < d16.rows; r++)
             for (int c = 0; c < d16.cols; c++) depth.ptr<float>(r)[c] = d16.ptr<int16_t>(r)[c] * (1.f / 16.f);
         return depth;
     }
-    last_rc = sv_depth_host(ctx, d16.ptr<int16_t>(), d16.step(), mapper.ptr<float>(), stereo->getQ(), stereo->getRLrect(),
-                            depth.ptr<float>(), depth.step());
+    last_rc = sv_depth_host(ctx, d16.ptr<int16_t>(), d16.step(), dev_mapper ? nullptr : mapper.ptr<float>(), stereo->getQ().ptr<double>(),
+                            stereo->getRLrect().ptr<double>(), depth.ptr<float>(), depth.step());
     if (last_rc) std::cout << "[StereoMatcherNew] !! depth failed: " << sv_last_error(ctx) << std::endl;
     return depth;
+}
+
+// ---- StereoCamera test double (see the header) ----
+void StereoCamera::setImages(const Image& firstImg, const Image& secondImg) {
+    imleft = firstImg;
+    imright = secondImg;
+}
+
+void StereoCamera::setIntrinsics(const Image& K1, const Image& K2, const Image& Dist1, const Image& Dist2) {
+    Kleft = K1; Kright = K2; DistL = Dist1; DistR = Dist2;
+    cameraChanged = true;  // stereoCamera.cpp:1949
+}
+
+void StereoCamera::setRectification(const Image& RL, const Image& RR, const Image& PL, const Image& PR, const Image& Qm) {
+    RLrect = RL; RRrect = RR; PLrect = PL; PRrect = PR; Q = Qm;
+    cameraChanged = true;  // the kinematics do this on every frame (DispModule.cpp:684 -> stereoCamera.cpp:1505-1536)
+}
+
+void StereoCamera::rectifyImages() {
+    if (imleft.empty() || imright.empty()) { std::cout << "Images are not set! set the images first!" << std::endl; return; }  // stereoCamera.cpp:554-557
+    // cameraChanged: cv::stereoRectify (stereoCamera.cpp:564) - its result comes from setRectification here
+    if (rectifyOnDevice) {                                      // PATCH B: no map generation, no remap on the CPU
+        if (cameraChanged) rectificationChanged = true;
+        cameraChanged = false;
+        return;
+    }
+    // stereoCamera.cpp:569-574: cv::initUndistortRectifyMap x2 + cv::remap x2.  No OpenCV in this build: the CPU path
+    // of this test double serves pairs that are rectified already, for which the remaps are copies.
+    imgLeftRect = imleft;
+    imgRightRect = imright;
+    cameraChanged = false;
+}
+
+void StereoCamera::updateMappings() {
+    const int rows = imleft.rows, cols = imleft.cols;
+    if (!cameraChanged || rectifyOnDevice || rows == 0) return;  // PATCH B: the mapper is made on the device
+    // stereoCamera.cpp:2443-2470: cv::undistortPoints on the pixel grid; for a pair that is rectified already the
+    // result is the grid itself
+    if (MapperL.rows != rows || MapperL.cols != cols) {
+        MapperL = Image(rows, cols, 2, 4);
+        for (int y = 0; y < rows; y++)
+            for (int x = 0; x < cols; x++) { MapperL.ptr<float>(y)[2 * x] = (float)x; MapperL.ptr<float>(y)[2 * x + 1] = (float)y; }
+        MapperR = MapperL;
+    }
 }
 
 }  // namespace svh

@@ -5,6 +5,12 @@
 // type because OpenCV/YARP are not available in this build environment.  In the real module the
 // only addition is matchSGBMHIP() + the enum value; this file shows that code
 // compiling and running against libsv_hip.
+//
+// The StereoCamera below exposes ONLY what the reference's class makes public
+// (lib/include/iCub/stereoVision/stereoCamera.h:181-600; each member cites its line), so that
+// matchSGBMHIP() as written here compiles against the unmodified reference (INTEGRATION.md,
+// variant A).  The four members marked PATCH B are the additions of INTEGRATION.md's variant B
+// (maps, remap and mapper on the GPU) and exist in the reference only after that patch.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -14,7 +20,7 @@
 
 namespace svh {
 
-// Stand-in for a continuous cv::Mat: CV_8UC1 / CV_8UC3 / CV_16SC1 / CV_32FC1 / CV_32FC2.
+// Stand-in for a continuous cv::Mat: CV_8UC1 / CV_8UC3 / CV_16SC1 / CV_32FC1 / CV_32FC2 / CV_64FC1.
 struct Image {
     int rows = 0, cols = 0, channels = 1, elem = 1;  // elem = bytes per channel element
     std::vector<uint8_t> data;
@@ -22,9 +28,15 @@ struct Image {
     Image(int r, int c, int ch, int e) : rows(r), cols(c), channels(ch), elem(e), data((size_t)r * c * ch * e) {}
     bool empty() const { return data.empty(); }
     size_t step() const { return (size_t)cols * channels * elem; }
+    size_t total() const { return (size_t)rows * cols; }
     template <class T> T* ptr(int r = 0) { return reinterpret_cast<T*>(data.data() + (size_t)r * step()); }
     template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data.data() + (size_t)r * step()); }
     Image clone() const { return *this; }
+    static Image mat64(int r, int c, const double* v) {
+        Image m(r, c, 1, 8);
+        for (int i = 0; i < r * c; i++) m.ptr<double>()[i] = v[i];
+        return m;
+    }
 };
 
 // StereoMatcher.h:27-49 with the new back-end appended so persisted values 0/1/2 keep their meaning
@@ -43,30 +55,50 @@ struct Params {
     SM_MATCHING_ALG stereo_matching = SGBM_HIP;
 };
 
-// The slice of StereoCamera (lib/include/iCub/stereoVision/stereoCamera.h) the matcher reads:
-// images, rectification maps (what initUndistortRectifyMap produced, stereoCamera.cpp:569-570), Q,
-// RLrect, MapperL.  Map generation itself stays with the caller.
+// The PUBLIC slice of StereoCamera the matcher path uses; data members are private as in the
+// reference (stereoCamera.h:93-178).  Test double: without OpenCV this class cannot run
+// cv::stereoRectify / cv::initUndistortRectifyMap / cv::remap / cv::undistortPoints, so
+//  * the result of cv::stereoRectify (stereoCamera.cpp:564) is handed in by the harness
+//    (setRectification, not a member of the reference), and
+//  * on the CPU path (variant A) rectifyImages() / updateMappings() only serve pairs that are
+//    rectified already: the two remaps are copies and the mapper is the identity grid.
 class StereoCamera {
 public:
-    void setImages(const Image& left, const Image& right) { imleft = left; imright = right; }
-    void setRectifyMaps(const Image& m11, const Image& m12, const Image& m21, const Image& m22) {
-        map11 = m11; map12 = m12; map21 = m21; map22 = m22; cameraChanged = true;
-    }
-    void setQ(const double q[16]) { for (int i = 0; i < 16; i++) Q[i] = q[i]; }
-    void setRLrect(const double r[9]) { for (int i = 0; i < 9; i++) RLrect[i] = r[i]; }
-    void setMapperL(const Image& m) { MapperL = m; }
-    const Image& getImLeft() const { return imleft; }
-    const Image& getImRight() const { return imright; }
-    const Image& getLRectified() const { return imgLeftRect; }
-    const Image& getRRectified() const { return imgRightRect; }
-    const double* getQ() const { return Q; }
-    const double* getRLrect() const { return RLrect; }
-    const Image& getMapperL() const { return MapperL; }
-    bool hasMaps() const { return !map11.empty(); }
+    void setImages(const Image& firstImg, const Image& secondImg);                   // stereoCamera.h:238
+    void setIntrinsics(const Image& K1, const Image& K2, const Image& Dist1, const Image& Dist2);  // :501
+    void rectifyImages();                                                            // :507  (stereoCamera.cpp:548-578)
+    void updateMappings();                                                           // stereoCamera.cpp:2437-2472
+    const Image& getImLeft() const { return imleft; }                                // :370
+    const Image& getImRight() const { return imright; }                              // :376
+    const Image& getLRectified() const { return imgLeftRect; }                       // :513
+    const Image& getRRectified() const { return imgRightRect; }                      // :519
+    const Image& getQ() const { return Q; }                                          // :406
+    const Image& getKleft() const { return Kleft; }                                  // :412
+    const Image& getKright() const { return Kright; }                                // :418
+    const Image& getDistCoeffLeft() const { return DistL; }                          // :547
+    const Image& getDistCoeffRight() const { return DistR; }                         // :541
+    const Image& getRLrect() const { return RLrect; }                                // :466
+    const Image& getRRrect() const { return RRrect; }                                // :472
+    const Image& getMapperL() const { return MapperL; }                              // :454
+    const Image& getMapperR() const { return MapperR; }                              // :460
 
-    Image imleft, imright, imgLeftRect, imgRightRect, map11, map12, map21, map22, MapperL;
-    double Q[16] = {0}, RLrect[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    bool cameraChanged = false;  // set by setRotation/setTranslation in the reference (stereoCamera.cpp:1505-1536)
+    // ---- PATCH B (variant B): not in the reference ----
+    const Image& getPLrect() const { return PLrect; }
+    const Image& getPRrect() const { return PRrect; }
+    void setRectifyOnDevice(bool on) { rectifyOnDevice = on; }  // rectifyImages() keeps cv::stereoRectify, skips map generation and remap
+    bool takeRectificationChanged() { const bool c = rectificationChanged; rectificationChanged = false; return c; }
+    bool getRectifyOnDevice() const { return rectifyOnDevice; }
+    void setMapperL(const Image& m) { MapperL = m; }  // what sv_get_mapper_host read back (getMapperL users: get3DPoints, DispModule.cpp:1103-1197)
+
+    // ---- test double only: what cv::stereoRectify writes at stereoCamera.cpp:564, and the cameraChanged flag that
+    // setRotation / setTranslation raise on every frame (stereoCamera.cpp:1505-1536) ----
+    void setRectification(const Image& RL, const Image& RR, const Image& PL, const Image& PR, const Image& Qm);
+
+private:
+    Image imleft, imright, imgLeftRect, imgRightRect;
+    Image Kleft, Kright, DistL, DistR, RLrect, RRrect, PLrect, PRrect, Q, MapperL, MapperR;
+    bool cameraChanged = true;
+    bool rectifyOnDevice = false, rectificationChanged = false;  // PATCH B
 };
 
 class StereoMatcherNew {
@@ -100,7 +132,7 @@ private:
     int device;
     sv_ctx* ctx = nullptr;
     int ctx_w = 0, ctx_h = 0;
-    bool maps_uploaded = false;
+    bool mapper_on_device = false;
     int last_rc = 0;
     Image disparity, disparity16, disparity_blf, disparity16_blf, disparity_wls, disparity16_wls;
     Params stereo_parameters;

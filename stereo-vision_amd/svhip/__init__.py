@@ -33,7 +33,7 @@ EXPORTS = (
     "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_filter_blf_joint_dev", "sv_filter_blf_joint_host", "sv_compute_rgb_batch_dev", "sv_disparity_vis_batch_dev", "sv_depth_batch_dev", "sv_world_image_dev", "sv_world_image_host",
     "sv_synchronize", "sv_last_aggregation", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
-    "sv_algorithmic_bytes", "sv_last_error", "sv_version", "sv_get_aggregation_timings", "sv_filter_speckles_static_dev", "sv_last_sweep_waves")
+    "sv_algorithmic_bytes", "sv_last_error", "sv_version", "sv_get_aggregation_timings", "sv_filter_speckles_static_dev", "sv_last_sweep_waves", "sv_compute_rgb_vis_host")
 STATIC_MAX_PIXELS = 1920 * 1088   # SV_STATIC_MAX_PIXELS
 
 
@@ -100,6 +100,7 @@ def load():
     L.sv_upload_maps_host.argtypes = [vp, vp, vp, vp, vp]
     L.sv_remap_rgb_dev.argtypes = [vp, i32, vp, vp]
     L.sv_compute_rgb_host.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz]
+    L.sv_compute_rgb_vis_host.argtypes = [vp, vp, sz, vp, sz, i32, vp, sz, vp, sz, i32]
     L.sv_get_rectified_host.argtypes = [vp, i32, vp, sz]
     L.sv_disparity_vis_dev.argtypes = [vp, vp, vp, i32]
     L.sv_disparity_vis_host.argtypes = [vp, vp, vp, i32]
@@ -262,6 +263,17 @@ class Matcher:
         self._chk(self._L.sv_compute_rgb_host(self._h, _ptr(left_rgb), 3 * self.W, _ptr(right_rgb), 3 * self.W,
                                               int(rectify), _ptr(out), 2 * self.W))
         return out
+
+    def compute_rgb_vis(self, left_rgb, right_rgb, rectify=True, scale=3):
+        """compute_rgb + getDisparityVis(.,.,scale) in one call -> (disp16, vis)."""
+        left_rgb = np.ascontiguousarray(left_rgb, np.uint8)
+        right_rgb = np.ascontiguousarray(right_rgb, np.uint8)
+        assert left_rgb.shape == (self.H, self.W, 3) and right_rgb.shape == (self.H, self.W, 3)
+        out = np.empty((self.H, self.W), np.int16)
+        vis = np.empty((self.H, self.W), np.uint8)
+        self._chk(self._L.sv_compute_rgb_vis_host(self._h, _ptr(left_rgb), 3 * self.W, _ptr(right_rgb), 3 * self.W,
+                                                  int(rectify), _ptr(out), 2 * self.W, _ptr(vis), self.W, scale))
+        return out, vis
 
     def rectified(self, which):
         out = np.empty((self.H, self.W, 3), np.uint8)

@@ -1,0 +1,131 @@
+"""GPU test of the C++ host shim (stereo-vision_amd/host): sv_module_sim replays the call order of
+DispModule::updateModule() (DispModule.cpp:661-814) - setImages, compute(), filterBLF("base"),
+filterWLS("blf"), getDisparity("wls"), getDisparity16("wls"), depthFromDisparity - through the mirror of
+StereoMatcherNew that calls libsv_hip, and dumps every product of the last frame; each is compared with
+the oracle fed with the same pair.
+
+Variant A: the matcher reads the pair StereoCamera has rectified on the CPU, through the
+reference's public getters only (the pair is rectified already, the test double's remap is a copy).
+Variant B: raw pair + camera matrices, maps / remap / mapper on the GPU: BASELINE.json configs[2] end to
+end at 640x480 D=128 with the module's defaults (speckle 50/16, BLF, WLS, vis, depth)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import svref
+import svhip
+from svhip import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM = os.path.join(ROOT, "stereo-vision_amd", "host", "sv_module_sim")
+
+
+def _oracle_params(D):
+    # what updateHIPParams() pushes: module defaults (DispModule.cpp:369-394), MODE_HH variant, speckle 50/16
+    ph = svhip.default_params(D, 8, speckle_window_size=50, speckle_range=16)
+    po = svref.Params()
+    for f, _t in svhip.Params._fields_:
+        setattr(po, f, getattr(ph, f))
+    return po
+
+
+def _run(tmp_path, W, H, D, wls, blf, lrgb, rrgb, mode, cam_text=None):
+    assert os.path.exists(SIM), "host shim not built (make -C stereo-vision_amd/host)"
+    fin, fout = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    with open(fin, "wb") as f:
+        f.write(np.ascontiguousarray(lrgb).tobytes())
+        f.write(np.ascontiguousarray(rrgb).tobytes())
+    cmd = [SIM, str(W), str(H), str(D), "2", "8", str(wls), str(blf), "--mode", mode, "--in", fin, "--out", fout, "--breakdown"]
+    if cam_text is not None:
+        fcam = str(tmp_path / "cam.txt")
+        open(fcam, "w").write(cam_text)
+        cmd += ["--cam", fcam]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(fout, np.uint8)
+    n, o, out = W * H, 0, {}
+    for name, dt in (("d16", np.int16), ("vis", np.uint8), ("d16_blf", np.int16), ("vis_blf", np.uint8), ("d16_wls", np.int16),
+                     ("vis_wls", np.uint8), ("depth", np.float32)):
+        nb = n * np.dtype(dt).itemsize
+        out[name] = raw[o:o + nb].view(dt).reshape(H, W)
+        o += nb
+    assert o == raw.size
+    return out, r.stdout
+
+
+def _expected(D, W, H, rl, rr, wls, blf, mapper, Q, RL):
+    po = _oracle_params(D)
+    e = {}
+    e["d16"] = svref.sgbm(svref.gray_from_rgb(rl), svref.gray_from_rgb(rr), po)   # speckle filter included (po.speckle_window_size)
+    e["vis"] = svref.disparity_vis(e["d16"], 3)
+    if blf == 1:
+        e["d16_blf"] = svref.blf(e["d16"], 10.0, 10.0)
+        e["vis_blf"] = svref.disparity_vis(e["d16_blf"], 3)
+    elif blf == 2:
+        e["d16_blf"] = svref.blf_joint(e["d16"], svref.gray_from_rgb(rl), D, 10.0, 7, 2)
+        e["vis_blf"] = svref.disparity_vis(e["d16_blf"], 3)
+    else:
+        e["d16_blf"], e["vis_blf"] = e["d16"], e["vis"]
+    if wls:
+        e["d16_wls"], e["vis_wls"] = svref.wls_filter(e["d16_blf"], rl, svref.wls_roi(W, H, po), 4500.0, 1.0, vis=e["vis_blf"])
+    else:
+        e["d16_wls"], e["vis_wls"] = e["d16_blf"], e["vis_blf"]
+    e["depth"] = svref.depth(e["d16_wls"], mapper, Q, RL, alias=False)
+    return e
+
+
+def _compare(got, exp):
+    for k in ("d16", "vis", "d16_blf", "vis_blf", "d16_wls", "vis_wls"):
+        assert np.array_equal(got[k], exp[k]), "%s differs in %d pixels" % (k, int((got[k] != exp[k]).sum()))
+    fin = np.isfinite(exp["depth"])
+    assert np.array_equal(np.isfinite(got["depth"]), fin)
+    rel = np.abs(got["depth"][fin] - exp["depth"][fin]) / np.maximum(np.abs(exp["depth"][fin]), 1e-12)
+    assert np.quantile(rel, 0.999) <= 1e-4   # <= 1e-4 relative (north star); a mapper value within 1 ulp of x.5 may round to the other pixel
+
+
+@pytest.mark.parametrize("wls,blf", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2)])
+def test_module_call_order_variant_a(gpu, tmp_path, wls, blf):
+    W, H, D = 320, 240, 64
+    left, right, _ = synth.stereo_pair(701, W, H, D)
+    rng = np.random.default_rng(7)
+    lrgb, rrgb = synth.rgb_from_gray(rng, left), synth.rgb_from_gray(rng, right)
+    got, log = _run(tmp_path, W, H, D, wls, blf, lrgb, rrgb, "a")
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    mapper = np.stack([xx, yy], -1)
+    fx, b = 0.7 * W, 0.068
+    Q = np.array([[1, 0, 0, -(W // 2 - 0.5)], [0, 1, 0, -(H // 2 - 0.5)], [0, 0, 0, fx], [0, 0, 1 / b, 0]], np.float64)
+    exp = _expected(D, W, H, lrgb, rrgb, wls, blf, mapper, Q, np.eye(3))
+    _compare(got, exp)
+    assert (got["d16"][:, D:] >= 0).mean() > 0.5
+
+
+def _cam_text(cams, Q):
+    vals = []
+    for K, dist, R, P in cams:
+        vals.append(float(len(np.asarray(dist).ravel())))
+        for a in (K, dist, R, P):
+            vals += [float(v) for v in np.asarray(a, np.float64).ravel()]
+    vals += [float(v) for v in np.asarray(Q, np.float64).ravel()]
+    return " ".join(repr(v) for v in vals)
+
+
+@pytest.mark.parametrize("wls,blf", [(1, 0), (1, 1)])
+def test_module_call_order_variant_b_c3_full_size(gpu, tmp_path, wls, blf):
+    W, H, D = 640, 480, 128
+    left, right, _ = synth.stereo_pair(303, W, H, D)
+    rng = np.random.default_rng(3)
+    lrgb, rrgb = synth.rgb_from_gray(rng, left), synth.rgb_from_gray(rng, right)
+    cams = [synth.camera(W, H, i) for i in (0, 1)]
+    fx, b = 0.7 * W, 0.068
+    Q = np.array([[1, 0, 0, -(W / 2 - 0.5)], [0, 1, 0, -(H / 2 - 0.5)], [0, 0, 0, fx], [0, 0, 1 / b, 0]], np.float64)
+    got, log = _run(tmp_path, W, H, D, wls, blf, lrgb, rrgb, "b", _cam_text(cams, Q))
+    maps = [svref.init_rectify_map(*cam, W, H) for cam in cams]
+    rl, rr = svref.remap_rgb(lrgb, *maps[0]), svref.remap_rgb(rrgb, *maps[1])
+    exp = _expected(D, W, H, rl, rr, wls, blf, svref.undistort_grid(*cams[0], W, H), Q, cams[0][2])
+    _compare(got, exp)
+    # (two differently distorted synthetic cameras over a pair that was row-aligned to begin with: a quarter of the pixels match)
+    assert (got["d16"][:, D:] >= 0).mean() > 0.1
