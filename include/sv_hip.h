@@ -92,7 +92,11 @@ typedef enum sv_status {
  * builds the clip table only once).
  */
 typedef struct sv_params {
-    int32_t min_disparity;       /* must be 0 (module default, DispModule.cpp:377)      */
+    int32_t min_disparity;       /* minDisparity of cv::StereoSGBM (StereoMatcher.cpp:399; RPC setMinDisp, DispModule.cpp:1355-1420;
+                                    module default 0, DispModule.cpp:377), -1024..1024.  EXT item (the CUDA back-end has no such
+                                    parameter): computable columns [max(minD + D, 0), W + min(minD, 0)), cost index d pairs left
+                                    x with right x - d - minD, disparity16 = (d + minD) * 16 + sub-pixel, every other pixel is
+                                    (minD - 1) * 16 (= SV_INVALID_DISP_SCALED for minD = 0)                                  */
     int32_t num_disparities;     /* D: multiple of 32, 32..256 (DispModule.cpp:1355-1420) */
     int32_t block_size;          /* SADWindowSize, odd, 1..11                            */
     int32_t P1;                  /* 8*BS*BS  (StereoMatcher.cpp:279)                     */
@@ -139,8 +143,8 @@ int sv_synchronize(sv_ctx* ctx);
 
 /* Replaces zy_remap / compute_disparity (main.cpp:106-109, bova_sgm.cu:43-328):
  * 8-bit gray rectified pair in host memory -> disparity16 in host memory.
- * Columns [0, D) are written as SV_INVALID_DISP_SCALED (the reference leaves
- * them uninitialised, bova_sgm.cu:67).                                        */
+ * Columns [0, D) (min_disparity = 0; see sv_params for other values) are written as
+ * SV_INVALID_DISP_SCALED (the reference leaves them uninitialised, bova_sgm.cu:67). */
 int sv_compute_gray_host(sv_ctx* ctx, const uint8_t* left_host, size_t left_stride,
                          const uint8_t* right_host, size_t right_stride,
                          int16_t* disp16_host, size_t disp_stride);
@@ -369,7 +373,7 @@ int sv_world_image_host(sv_ctx* ctx, const int16_t* disp16_host, size_t disp_str
 
 /* Stage access for parity tests and profiling (no counterpart in the
  * reference beyond the #if 0 dump blocks, bova_sgm.cu:141-321).  Copies the
- * internal [H][W-D][D] int16 volumes of the LAST sv_compute_* call to host.
+ * internal [H][W1][D] int16 volumes (W1 = computable columns = W - D for min_disparity 0) of the LAST sv_compute_* call to host.
  * which: 0 = C (matching cost + P2), 1 = S (aggregated).  S is only complete in
  * debug mode.  sv_set_debug modes: 0 = production (batches of >= 6 frames fuse
  * WTA into the last path, which then keeps the finished S in registers and

@@ -55,28 +55,34 @@ def _halfpel_minmax(row):
     return v, np.minimum(np.minimum(vl, vr), v), np.maximum(np.maximum(vl, vr), v)
 
 
-def bt_cost(L, R, D, shift):
+def columns(W, D, minD):
+    """computable columns [col0, colN) for a disparity range [minD, minD + D) (EXT: cv::StereoSGBM minDisparity)."""
+    return max(minD + D, 0), W + min(minD, 0)
+
+
+def bt_cost(L, R, D, shift, minD=0):
     """A2 for one channel -> [H][W1][D] int32."""
     H, W = L.shape
-    W1 = W - D
+    col0, colN = columns(W, D, minD)
+    W1 = colN - col0
     out = np.zeros((H, W1, D), np.int32)
     for y in range(H):
         u, u0, u1 = _halfpel_minmax(L[y])
         v, v0, v1 = _halfpel_minmax(R[y])
         for d in range(D):
-            xs = np.arange(D, W)
-            xr = xs - d
+            xs = np.arange(col0, colN)
+            xr = xs - (d + minD)
             c0 = np.maximum(np.maximum(0, u[xs] - v1[xr]), v0[xr] - u[xs])
             c1 = np.maximum(np.maximum(0, v[xr] - u1[xs]), u0[xs] - v[xr])
             out[y, :, d] = np.minimum(c0, c1) >> shift
     return out
 
 
-def cost_volume(left, right, D, BS, P2, cap, flags=0):
+def cost_volume(left, right, D, BS, P2, cap, flags=0, minD=0):
     """A2-A4 as direct clamped-window sums."""
     gl, rl = prefilter(left, cap)
     gr, rr = prefilter(right, cap)
-    pix = bt_cost(gl, gr, D, 0) + bt_cost(rl, rr, D, 2)
+    pix = bt_cost(gl, gr, D, 0, minD) + bt_cost(rl, rr, D, 2, minD)
     H, W1, _ = pix.shape
     r = BS // 2
     hs = np.zeros_like(pix)
@@ -134,17 +140,18 @@ def aggregate(C, P1, P2, path_mask):
     return S.astype(np.int16), Ls
 
 
-def wta(S, W, uniq):
-    """A6 -> disp, raw, mins (full width)."""
+def wta(S, W, uniq, minD=0):
+    """A6 -> disp, raw, mins (full width).  raw is the cost index; disp carries minD (EXT)."""
     H, W1, D = S.shape
-    disp = np.full((H, W), INVALID, np.int16)
+    col0 = columns(W, D, minD)[0]
+    disp = np.full((H, W), (minD - 1) * 16, np.int16)
     raw = np.full((H, W), -1, np.int16)
     mins = np.full((H, W), 32767, np.int16)
     ds = np.arange(D)
     for y in range(H):
         for xl in range(W1):
             s = S[y, xl].astype(np.int64)
-            x = xl + D
+            x = xl + col0
             minS = int(s.min())
             if minS >= 32767:
                 continue
@@ -157,35 +164,38 @@ def wta(S, W, uniq):
                 den = max(int(s[best - 1] + s[best + 1] - 2 * s[best]), 1)
                 num = int(s[best - 1] - s[best + 1]) * 16 + den
                 q = abs(num) // (2 * den)  # C division truncates toward zero
-                disp[y, x] = best * 16 + (q if num >= 0 else -q)
+                disp[y, x] = (best + minD) * 16 + (q if num >= 0 else -q)
             else:
-                disp[y, x] = best * 16
+                disp[y, x] = (best + minD) * 16
     return disp, raw, mins
 
 
-def lrcheck(disp, raw, mins, D, thresh):
-    """A7."""
+def lrcheck(disp, raw, mins, D, thresh, minD=0):
+    """A7 (with min_disparity as cv::StereoSGBM has it: disp2 holds true disparities, none = minD - 1)."""
     H, W = disp.shape
+    col0, colN = columns(W, D, minD)
+    inv = (minD - 1) * 16
     out = disp.copy()
     for y in range(H):
-        d2 = np.full(W, INVALID, np.int32)
+        d2 = np.full(W, minD - 1, np.int32)
         c2 = np.full(W, 32767, np.int32)
-        for x in range(W - 1, D - 1, -1):
+        for x in range(colN - 1, col0 - 1, -1):
             d = int(raw[y, x])
             if d < 0:
                 continue
-            if c2[x - d] > mins[y, x]:
-                c2[x - d] = mins[y, x]
-                d2[x - d] = d
-        for x in range(D, W):
+            x2 = x - d - minD
+            if c2[x2] > mins[y, x]:
+                c2[x2] = mins[y, x]
+                d2[x2] = d + minD
+        for x in range(col0, colN):
             d1 = int(disp[y, x])
-            if d1 == INVALID:
+            if d1 == inv:
                 continue
             lo, hi = d1 >> 4, (d1 + 15) >> 4
             xa, xb = x - lo, x - hi
-            if (0 <= xa < W and d2[xa] >= 0 and abs(d2[xa] - lo) > thresh and 0 <= xb < W and d2[xb] >= 0
+            if (0 <= xa < W and d2[xa] >= minD and abs(d2[xa] - lo) > thresh and 0 <= xb < W and d2[xb] >= minD
                     and abs(d2[xb] - hi) > thresh):
-                out[y, x] = INVALID
+                out[y, x] = inv
     return out
 
 
@@ -230,23 +240,23 @@ def filter_speckles(img, new_val, max_size, max_diff):
 
 
 def sgbm(left, right, D, BS=7, P1=None, P2=None, cap=63, uniq=15, disp12=0, path_mask=0x1F, flags=0,
-         speckle_window=0, speckle_range=0):
+         speckle_window=0, speckle_range=0, minD=0):
     P1 = 8 * BS * BS if P1 is None else P1
     P2 = 32 * BS * BS if P2 is None else P2
     H, W = left.shape
-    C, st = cost_volume(left, right, D, BS, P2, cap, flags)
+    C, st = cost_volume(left, right, D, BS, P2, cap, flags, minD)
     S, Ls = aggregate(C, P1, P2, path_mask)
-    disp, raw, mins = wta(S, W, uniq)
+    disp, raw, mins = wta(S, W, uniq, minD)
     st.update(C=C, S=S, L=Ls, disp_wta=disp, raw=raw, mins=mins)
     if not flags & FLAG_NO_LRCHECK:
         thr = disp12
         if flags & FLAG_LR_OPENCV:
             thr = thr if thr > 0 else 1
-        disp = lrcheck(disp, raw, mins, D, thr)
+        disp = lrcheck(disp, raw, mins, D, thr, minD)
     st["disp_lr"] = disp
     if not flags & FLAG_NO_MEDIAN:
         disp = median3(disp, bool(flags & FLAG_MEDIAN_REPLICATE))
     st["disp_med"] = disp
     if speckle_window > 0:
-        disp = filter_speckles(disp, INVALID, speckle_window, 16 * speckle_range)
+        disp = filter_speckles(disp, (minD - 1) * 16, speckle_window, 16 * speckle_range)
     return disp, st

@@ -224,6 +224,16 @@ int svref_blf_joint(const int16_t* disp, const uint8_t* guide, int W, int H, int
 
 const char* svref_version(void) { return "sv_ref 1 (restated SGBM, parity unpinned)"; }
 
+/* min_disparity (EXT: cv::StereoSGBM, as matchSGBM passes it, StereoMatcher.cpp:399; the CUDA back-end has no
+ * such parameter).  OpenCV's computeDisparitySGBM: minD = minDisparity, maxD = minD + numDisparities; the
+ * computable columns are x in [minX1, maxX1) = [max(maxD, 0), W + min(minD, 0)); cost index d (0..D-1) pairs
+ * left x with right x - d - minD; the stored disparity is (d + minD) * 16 + sub-pixel; every other pixel is
+ * INVALID_DISP_SCALED = (minD - 1) * 16. */
+static int geo_col0(int W, int D, int minD) { (void)W; return imax(minD + D, 0); }
+static int geo_colN(int W, int D, int minD) { (void)D; return W + imin(minD, 0); }
+static int geo_w1(int W, int D, int minD) { return geo_colN(W, D, minD) - geo_col0(W, D, minD); }
+static int geo_invalid(int minD) { return (minD - 1) * 16; }
+
 /* Limits under which every int16 store of the reference is wrap-free, so the
  * restatement (and the GPU) may compute windows directly instead of through
  * the reference's running sums.  Even block sizes are rejected (Appendix A9b:
@@ -231,10 +241,10 @@ const char* svref_version(void) { return "sv_ref 1 (restated SGBM, parity unpinn
 int svref_check_params(const svref_params* p, int W, int H) {
     if (!p) return -1;
     int D = p->num_disparities, BS = p->block_size;
-    if (p->min_disparity != 0) return -2;
+    if (p->min_disparity < -1024 || p->min_disparity > 1024) return -2; /* (minD - 1) * 16 and (minD + D) * 16 fit int16 */
     if (D < 32 || D > 256 || (D % 32) != 0) return -2;
     if (BS < 1 || BS > 11 || (BS % 2) == 0) return -2;
-    if (W <= D || H < BS || W - D < BS) return -1;
+    if (H < BS || geo_w1(W, D, p->min_disparity) < BS || geo_w1(W, D, p->min_disparity) < 1) return -1;
     if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63) return -2;
     if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return -2;
     /* max per-pixel BT cost: 2*cap (gradient channel) + 255>>2 (raw channel), per colour channel */
@@ -272,21 +282,22 @@ void svref_prefilter(const uint8_t* img, int W, int H, int cap, uint8_t* grad, u
 
 /* A2 REPO costs.cu:170-201 (get_pixel_diff), one channel, accumulated into
  * pix[y][xl][d] (int16 store at :199). */
-static void bt_channel(const uint8_t* L, const uint8_t* R, int W, int H, int D, int shift, int16_t* pix) {
-    const int W1 = W - D;
+static void bt_channel(const uint8_t* L, const uint8_t* R, int W, int H, int D, int minD, int shift, int16_t* pix) {
+    const int col0 = geo_col0(W, D, minD), colN = geo_colN(W, D, minD), W1 = colN - col0;
     for (int y = 0; y < H; y++) {
         const uint8_t* l = L + (size_t)y * W;
         const uint8_t* r = R + (size_t)y * W;
-        for (int x = D; x < W; x++) {
+        for (int x = col0; x < colN; x++) {
             int u = l[x];
             int ul = x > 0 ? (u + l[x - 1]) / 2 : u;
             int ur = x < W - 1 ? (u + l[x + 1]) / 2 : u;
             int u0 = imin(imin(ul, ur), u), u1 = imax(imax(ul, ur), u);
-            int16_t* out = pix + ((size_t)y * W1 + (x - D)) * D;
+            int16_t* out = pix + ((size_t)y * W1 + (x - col0)) * D;
             for (int d = 0; d < D; d++) {
-                int v = r[x - d];
-                int vl = x >= d + 1 ? (r[x - d - 1] + v) / 2 : v;
-                int vr = x < W + d - 1 ? (r[x - d + 1] + v) / 2 : v;
+                const int xr = x - d - minD; /* in [1, W-1] for every computable x */
+                int v = r[xr];
+                int vl = xr >= 1 ? (r[xr - 1] + v) / 2 : v;
+                int vr = xr < W - 1 ? (r[xr + 1] + v) / 2 : v;
                 int v0 = imin(imin(vl, vr), v), v1 = imax(imax(vl, vr), v);
                 int c0 = imax(imax(0, u - v1), v0 - u);
                 int c1 = imax(imax(0, v - u1), u0 - v);
@@ -314,7 +325,7 @@ int svref_cost_volume(const uint8_t* left, const uint8_t* right, int W, int H, c
  * into one cost per (x, d).  Stage outputs grad / raw hold the LAST plane. */
 static int cost_volume_planes(const uint8_t* const* lefts, const uint8_t* const* rights, int cn, int W, int H,
                               const svref_params* p, int16_t* C, svref_stages* st) {
-    const int D = p->num_disparities, W1 = W - D, BS = p->block_size, SW2 = BS / 2, SH2 = BS / 2;
+    const int D = p->num_disparities, minD = p->min_disparity, W1 = geo_w1(W, D, minD), BS = p->block_size, SW2 = BS / 2, SH2 = BS / 2;
     const int P2 = p->P2;
     const size_t npx = (size_t)W * H, nvol = (size_t)W1 * H * D;
     uint8_t* gl = (uint8_t*)malloc(npx);
@@ -330,8 +341,8 @@ static int cost_volume_planes(const uint8_t* const* lefts, const uint8_t* const*
     for (int ch = 0; ch < cn; ch++) {
         svref_prefilter(lefts[ch], W, H, p->pre_filter_cap, gl, rl);
         svref_prefilter(rights[ch], W, H, p->pre_filter_cap, gr, rr);
-        bt_channel(gl, gr, W, H, D, 0, pix); /* bova_sgm.cu:95 */
-        bt_channel(rl, rr, W, H, D, 2, pix); /* bova_sgm.cu:97 */
+        bt_channel(gl, gr, W, H, D, minD, 0, pix); /* bova_sgm.cu:95 */
+        bt_channel(rl, rr, W, H, D, minD, 2, pix); /* bova_sgm.cu:97 */
     }
 
     /* A3 horizontal box, costs.cu:214-232 */
@@ -472,15 +483,19 @@ void svref_aggregate_path(const int16_t* C, int W1, int H, int D, int P1, int P2
  * [0,D) get the contract value (Appendix A9).  raw = -1 marks "no disparity"
  * (REPO writes INVALID_DISP_SCALED there, :642; same meaning). */
 void svref_wta(const int16_t* S, int W, int H, int D, int uniq, int16_t* disp, int16_t* raw, int16_t* mins) {
-    const int W1 = W - D;
+    svref_wta_min(S, W, H, D, 0, uniq, disp, raw, mins);
+}
+/* the same with min_disparity (EXT): raw stays the cost INDEX (0..D-1, -1 = none), disp carries minD */
+void svref_wta_min(const int16_t* S, int W, int H, int D, int minD, int uniq, int16_t* disp, int16_t* raw, int16_t* mins) {
+    const int col0 = geo_col0(W, D, minD), colN = geo_colN(W, D, minD), W1 = colN - col0;
     for (int y = 0; y < H; y++) {
         for (int x = 0; x < W; x++) {
             size_t o = (size_t)y * W + x;
-            disp[o] = SVREF_INVALID;
+            disp[o] = (int16_t)geo_invalid(minD);
             raw[o] = -1;
             mins[o] = SHRT_MAX_I;
-            if (x < D) continue;
-            const int16_t* s = S + ((size_t)y * W1 + (x - D)) * D;
+            if (x < col0 || x >= colN) continue;
+            const int16_t* s = S + ((size_t)y * W1 + (x - col0)) * D;
             int minS = SHRT_MAX_I, best = -1;
             for (int d = 0; d < D; d++)
                 if (minS > s[d]) { minS = s[d]; best = d; }
@@ -497,7 +512,7 @@ void svref_wta(const int16_t* S, int W, int H, int D, int uniq, int16_t* disp, i
                 v = best * 16 + ((s[best - 1] - s[best + 1]) * 16 + denom2) / (denom2 * 2);
             } else
                 v = best * 16;
-            disp[o] = (int16_t)v;
+            disp[o] = (int16_t)(v + minD * 16);
         }
     }
 }
@@ -506,27 +521,33 @@ void svref_wta(const int16_t* S, int W, int H, int D, int uniq, int16_t* disp, i
  * with a strict '>' so ties keep the larger x (:706-719). */
 void svref_lrcheck(int16_t* disp, const int16_t* raw, const int16_t* mins, int W, int H, int D, int thresh,
                    int16_t* disp2_out) {
+    svref_lrcheck_min(disp, raw, mins, W, H, D, 0, thresh, disp2_out);
+}
+/* with min_disparity (EXT): disp2 holds true disparities (index + minD), "none" = minD - 1 */
+void svref_lrcheck_min(int16_t* disp, const int16_t* raw, const int16_t* mins, int W, int H, int D, int minD, int thresh,
+                       int16_t* disp2_out) {
+    const int col0 = geo_col0(W, D, minD), colN = geo_colN(W, D, minD), inv = geo_invalid(minD);
     int16_t* disp2 = (int16_t*)malloc(sizeof(int16_t) * W);
     int16_t* d2c = (int16_t*)malloc(sizeof(int16_t) * W);
     for (int y = 0; y < H; y++) {
         int16_t* dp = disp + (size_t)y * W;
         const int16_t* rw = raw + (size_t)y * W;
         const int16_t* mn = mins + (size_t)y * W;
-        for (int x = 0; x < W; x++) { d2c[x] = SHRT_MAX_I; disp2[x] = SVREF_INVALID; }
-        for (int x = W - 1; x >= D; x--) {
+        for (int x = 0; x < W; x++) { d2c[x] = SHRT_MAX_I; disp2[x] = (int16_t)(minD - 1); }
+        for (int x = colN - 1; x >= col0; x--) {
             int d = rw[x];
             if (d < 0) continue;
-            int x2 = x - d;
-            if (d2c[x2] > mn[x]) { d2c[x2] = mn[x]; disp2[x2] = (int16_t)d; }
+            int x2 = x - d - minD;
+            if (d2c[x2] > mn[x]) { d2c[x2] = mn[x]; disp2[x2] = (int16_t)(d + minD); }
         }
-        for (int x = D; x < W; x++) {
+        for (int x = col0; x < colN; x++) {
             int d1 = dp[x];
-            if (d1 == SVREF_INVALID) continue;
+            if (d1 == inv) continue;
             int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
             int _x = x - _d, x_ = x - d_;
-            if (0 <= _x && _x < W && disp2[_x] >= 0 && abs(disp2[_x] - _d) > thresh && 0 <= x_ && x_ < W &&
-                disp2[x_] >= 0 && abs(disp2[x_] - d_) > thresh)
-                dp[x] = SVREF_INVALID;
+            if (0 <= _x && _x < W && disp2[_x] >= minD && abs(disp2[_x] - _d) > thresh && 0 <= x_ && x_ < W &&
+                disp2[x_] >= minD && abs(disp2[x_] - d_) > thresh)
+                dp[x] = (int16_t)inv;
         }
         if (disp2_out) memcpy(disp2_out + (size_t)y * W, disp2, sizeof(int16_t) * W);
     }
@@ -628,7 +649,7 @@ static int sgbm_planes(const uint8_t* left, size_t ls, const uint8_t* right, siz
     int rc = svref_check_params(p, W, H);
     if (rc) return rc;
     if (!left || !right || !disp16 || ls < (size_t)W * cn || rs < (size_t)W * cn || ds < (size_t)W * 2) return -1;
-    const int D = p->num_disparities, W1 = W - D;
+    const int D = p->num_disparities, minD = p->min_disparity, W1 = geo_w1(W, D, minD);
     const size_t npx = (size_t)W * H, nvol = (size_t)W1 * H * D;
     uint8_t* l = (uint8_t*)malloc(npx * cn); /* cn planes */
     uint8_t* r = (uint8_t*)malloc(npx * cn);
@@ -656,14 +677,14 @@ static int sgbm_planes(const uint8_t* left, size_t ls, const uint8_t* right, siz
             if (p->path_mask & (1u << dir))
                 svref_aggregate_path(C, W1, H, D, p->P1, p->P2, dir, S, st ? st->L[dir] : NULL);
         if (st && st->S) memcpy(st->S, S, nvol * sizeof(int16_t));
-        svref_wta(S, W, H, D, p->uniqueness_ratio, disp, raw, mins);
+        svref_wta_min(S, W, H, D, minD, p->uniqueness_ratio, disp, raw, mins);
         if (st && st->disp_wta) memcpy(st->disp_wta, disp, npx * 2);
         if (st && st->raw) memcpy(st->raw, raw, npx * 2);
         if (st && st->mins) memcpy(st->mins, mins, npx * 2);
         if (!(p->flags & SVREF_FLAG_NO_LRCHECK)) {
             int thr = p->disp12_max_diff;
             if (p->flags & SVREF_FLAG_LR_OPENCV) thr = thr > 0 ? thr : 1; /* EXT, Appendix A7 */
-            svref_lrcheck(disp, raw, mins, W, H, D, thr, st ? st->disp2 : NULL);
+            svref_lrcheck_min(disp, raw, mins, W, H, D, minD, thr, st ? st->disp2 : NULL);
         }
         if (st && st->disp_lr) memcpy(st->disp_lr, disp, npx * 2);
         if (!(p->flags & SVREF_FLAG_NO_MEDIAN))
@@ -672,7 +693,7 @@ static int sgbm_planes(const uint8_t* left, size_t ls, const uint8_t* right, siz
             memcpy(med, disp, npx * 2);
         if (st && st->disp_med) memcpy(st->disp_med, med, npx * 2);
         if (p->speckle_window_size > 0)
-            svref_filter_speckles(med, W, H, SVREF_INVALID, p->speckle_window_size, 16 * p->speckle_range);
+            svref_filter_speckles(med, W, H, geo_invalid(minD), p->speckle_window_size, 16 * p->speckle_range);
         for (int y = 0; y < H; y++) memcpy((char*)disp16 + y * ds, med + (size_t)y * W, (size_t)W * 2);
     }
     free(l); free(r); free(C); free(S); free(disp); free(raw); free(mins); free(med);

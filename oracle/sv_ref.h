@@ -80,6 +80,12 @@ void svref_wta(const int16_t* S, int W, int H, int D, int uniq, int16_t* disp, i
 /* A7: aggregation.cu:691-735 */
 void svref_lrcheck(int16_t* disp, const int16_t* raw, const int16_t* mins, int W, int H, int D, int thresh,
                    int16_t* disp2_out);
+/* A6 / A7 with min_disparity (EXT, cv::StereoSGBM as matchSGBM parameterises it, StereoMatcher.cpp:399): the
+ * computable columns are [max(minD + D, 0), W + min(minD, 0)), cost index d pairs left x with right
+ * x - d - minD, stored disparity = (d + minD) * 16 + sub-pixel, invalid = (minD - 1) * 16; raw stays the index */
+void svref_wta_min(const int16_t* S, int W, int H, int D, int minD, int uniq, int16_t* disp, int16_t* raw, int16_t* mins);
+void svref_lrcheck_min(int16_t* disp, const int16_t* raw, const int16_t* mins, int W, int H, int D, int minD, int thresh,
+                       int16_t* disp2_out);
 /* A8: aggregation.cu:737-768 */
 void svref_median3(const int16_t* in, int16_t* out, int W, int H, int replicate);
 /* A10 (EXT cv::filterSpeckles) */

@@ -123,6 +123,13 @@ _STAGE_SPECS = {
     "disp_lr": ("px", np.int16), "disp_med": ("px", np.int16)}
 
 
+def geometry(W, params):
+    """(col0, colN, W1, invalid): computable columns [col0, colN), their count, the invalid marker (min_disparity, EXT)."""
+    D, minD = params.num_disparities, params.min_disparity
+    col0, colN = max(minD + D, 0), W + min(minD, 0)
+    return col0, colN, colN - col0, (minD - 1) * 16
+
+
 def sgbm(left, right, params, stages=(), path_L=False):
     """Run the oracle.  Returns disp16 [H][W] int16 (and a dict of requested stages)."""
     left = np.ascontiguousarray(left, np.uint8)
@@ -130,19 +137,20 @@ def sgbm(left, right, params, stages=(), path_L=False):
     rgb = left.ndim == 3          # [H][W][3]: matchSGBM semantics, needs FLAG_COST_RGB in params.flags
     H, W = left.shape[:2]
     D = params.num_disparities
+    W1 = geometry(W, params)[2]
     out = np.empty((H, W), np.int16)
     st = Stages()
     keep = {}
     for name in stages:
         kind, dt = _STAGE_SPECS[name]
-        arr = np.zeros((H, W) if kind == "px" else (H, W - D, D), dt)
+        arr = np.zeros((H, W) if kind == "px" else (H, W1, D), dt)
         keep[name] = arr
         setattr(st, name, _ptr(arr).value)
     if path_L:
         Ls = {}
         for k in range(8):
             if params.path_mask & (1 << k):
-                Ls[k] = np.zeros((H, W - D, D), np.int16)
+                Ls[k] = np.zeros((H, W1, D), np.int16)
                 st.L[k] = _ptr(Ls[k]).value
         keep["L"] = Ls
     fn = lib().svref_sgbm_rgb if rgb else lib().svref_sgbm
@@ -159,7 +167,7 @@ def cost_volume(left, right, params):
     right = np.ascontiguousarray(right, np.uint8)
     H, W = left.shape
     D = params.num_disparities
-    Cv = np.empty((H, W - D, D), np.int16)
+    Cv = np.empty((H, geometry(W, params)[2], D), np.int16)
     rc = lib().svref_cost_volume(_ptr(left), _ptr(right), W, H, C.byref(params), _ptr(Cv), None)
     if rc:
         raise ValueError("svref_cost_volume failed: %d" % rc)

@@ -161,17 +161,27 @@ int fail(sv_ctx* c, int code, const char* fmt, ...) {
             return fail((c), SV_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Geometry with min_disparity (EXT: cv::StereoSGBM as matchSGBM parameterises it, StereoMatcher.cpp:399; the CUDA
+// back-end has no such parameter): the computable columns are [max(minD + D, 0), W + min(minD, 0)), cost index d
+// pairs left x with right x - d - minD, invalid = (minD - 1) * 16.  minD = 0: columns [D, W).
+inline int geo_col0(int W, const sv_params& p) { (void)W; return std::max(p.min_disparity + p.num_disparities, 0); }
+inline int geo_colN(int W, const sv_params& p) { return W + std::min(p.min_disparity, 0); }
+inline int geo_w1(int W, const sv_params& p) { return geo_colN(W, p) - geo_col0(W, p); }
+inline int geo_inv(const sv_params& p) { return (p.min_disparity - 1) * 16; }
+
 int check_params(sv_ctx* c, const sv_params* p, int W, int H) {
     if (!p) return fail(c, SV_ERR_INVALID_ARG, "params is NULL");
     const int D = p->num_disparities, BS = p->block_size;
-    if (p->min_disparity != 0) return fail(c, SV_ERR_UNSUPPORTED, "min_disparity must be 0 (got %d)", p->min_disparity);
+    if (p->min_disparity < -1024 || p->min_disparity > 1024)
+        return fail(c, SV_ERR_UNSUPPORTED, "min_disparity must be in [-1024, 1024] (got %d)", p->min_disparity);
     if (D < 32 || D > 256 || (D % 32) != 0)
         return fail(c, SV_ERR_UNSUPPORTED, "num_disparities must be a multiple of 32 in [32,256] (got %d)", D);
     if (BS < 1 || BS > 11 || (BS % 2) == 0)
         return fail(c, SV_ERR_UNSUPPORTED, "block_size must be odd in [1,11] (got %d)", BS);
     // width: the LR check keeps one 4-byte key per column of a row in LDS (160 KB)
-    if (W <= D || H < BS || W - D < BS || W > 40000 || H > 65535)
-        return fail(c, SV_ERR_INVALID_ARG, "image %dx%d too small/large for D=%d block=%d (W <= 40000, H <= 65535)", W, H, D, BS);
+    if (D >= 32 && D <= 256 && (geo_w1(W, *p) < 1 || H < BS || geo_w1(W, *p) < BS || W > 40000 || H > 65535))
+        return fail(c, SV_ERR_INVALID_ARG, "image %dx%d too small/large for D=%d min_disparity=%d block=%d (W <= 40000, H <= 65535)", W, H, D,
+                    p->min_disparity, BS);
     if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63)
         return fail(c, SV_ERR_UNSUPPORTED, "pre_filter_cap must be in [1,63] (got %d)", p->pre_filter_cap);
     if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return fail(c, SV_ERR_INVALID_ARG, "need 0 <= P1 <= P2, P2 >= 1");
@@ -209,14 +219,14 @@ void release(Buf& b) {
 struct CoreSizes { size_t stat_l, stat_r, vol, rec, plane; };
 CoreSizes core_sizes(const sv_ctx* c, int nb) {
     const size_t npx = (size_t)c->W * c->H * nb;
-    const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities * nb;
+    const size_t nvol = (size_t)geo_w1(c->W, c->prm) * c->H * c->prm.num_disparities * nb;
     const size_t cn = (c->prm.flags & SV_FLAG_COST_RGB) ? 3 : 1;
     return CoreSizes{npx * 8 * cn, (size_t)6 * c->H * svk::cost_plane_pitch(c->W) * 2 * nb * cn, nvol * 2, npx * 8, npx * 2};
 }
 
 int alloc_core_once(sv_ctx* c) {
     const size_t npx = (size_t)c->W * c->H * c->batch;
-    const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities * c->batch;
+    const size_t nvol = (size_t)geo_w1(c->W, c->prm) * c->H * c->prm.num_disparities * c->batch;
     int rc;
     const size_t cn = (c->prm.flags & SV_FLAG_COST_RGB) ? 3 : 1;  // statistics per colour plane
     if ((rc = ensure(c, c->stat_l, npx * 8 * cn))) return rc;
@@ -278,7 +288,7 @@ template <int N>
 void launch_agg_n(sv_ctx* c, int dir, int mode, int nb, uint32_t* Sout, hipStream_t st) {
     static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
-    const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
+    const int W1 = geo_w1(c->W, c->prm), H = c->H;
     const int dx = DX[dir], dy = DY[dir];
     const bool vert = dy != 0;
     const int nchains = vert ? W1 : H;
@@ -290,7 +300,8 @@ void launch_agg_n(sv_ctx* c, int dir, int mode, int nb, uint32_t* Sout, hipStrea
     uint2* rec = (uint2*)c->rec.p;
     const int uq = c->prm.uniqueness_ratio;
 #define SV_LAUNCH_AGG(V, M) \
-    hipLaunchKernelGGL((svk::k_agg<N, V, M, U>), grid, block, 0, st, Cv, Sv, W1, H, dx, dy, P1P1, P2P2, rec, uq)
+    hipLaunchKernelGGL((svk::k_agg<N, V, M, U>), grid, block, 0, st, Cv, Sv, W1, H, dx, dy, P1P1, P2P2, rec, uq, c->W, \
+                       geo_col0(c->W, c->prm), c->prm.min_disparity)
     if (vert) {
         switch (mode) {
             case 0: SV_LAUNCH_AGG(true, 0); break;
@@ -325,14 +336,14 @@ void launch_agg(sv_ctx* c, int dir, int mode, int nb) { launch_agg_to(c, dir, mo
 
 template <int N>
 void launch_paths_sum_n(sv_ctx* c, const svk::PathSet& ps, const svk::PathBufs& pb, int nb) {
-    const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
+    const int W1 = geo_w1(c->W, c->prm), H = c->H;
     constexpr int U = N <= 4 ? 4 : 2;
     const int nch = W1 > H ? W1 : H;
     hipLaunchKernelGGL((svk::k_agg_paths<N, U>), dim3((nch + 3) / 4, nb, pb.n), dim3(64), 0, c->stream, (const uint32_t*)c->C.p, ps,
                        W1, H, (uint32_t)c->prm.P1 * 0x10001u, (uint32_t)c->prm.P2 * 0x10001u);
     const size_t npx = (size_t)W1 * H;
     hipLaunchKernelGGL((svk::k_sum_wta<N>), dim3((unsigned)((npx * 16 + 255) / 256), nb), dim3(256), 0, c->stream, pb,
-                       (uint2*)c->rec.p, c->W, c->H, c->prm.uniqueness_ratio);
+                       (uint2*)c->rec.p, c->W, c->H, c->prm.uniqueness_ratio, geo_col0(c->W, c->prm), W1, c->prm.min_disparity);
 }
 
 // Small batches are latency-bound (one path launch of one 640x480 frame is 128 waves on 1024
@@ -343,7 +354,7 @@ int run_paths_fanout(sv_ctx* c, int nb) {
     static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const sv_params& p = c->prm;
-    const size_t vol = (size_t)(c->W - p.num_disparities) * c->H * p.num_disparities * 2 * nb;
+    const size_t vol = (size_t)geo_w1(c->W, p) * c->H * p.num_disparities * 2 * nb;
     svk::PathSet ps;
     svk::PathBufs pb;
     pb.n = 0;
@@ -377,7 +388,7 @@ int launch_cost2_n(sv_ctx* c, int nb) {
     // CN = colour planes in the cost: 1 (gray) or 3 (SV_FLAG_COST_RGB)
     constexpr int NCOL = NT / 16;
     const sv_params& p = c->prm;
-    const int W = c->W, H = c->H, D = p.num_disparities, W1 = W - D, r = p.block_size / 2;
+    const int W = c->W, H = c->H, D = p.num_disparities, W1 = geo_w1(W, p), r = p.block_size / 2;
     const int TX = NCOL - 2 * r, WP = svk::cost_plane_pitch(W);
     if constexpr (NT == 512 && CN == 1 && N <= 4) {
         // Large batches: 64-column tiles (1024 threads, one workgroup per CU) recompute the 2r halo columns of the
@@ -410,7 +421,8 @@ int launch_cost2_n(sv_ctx* c, int nb) {
     if (n_wg > 0x7FFFFFFFu) return fail(c, SV_ERR_UNSUPPORTED, "batch too large for one cost launch");
     hipLaunchKernelGGL((svk::k_cost2<N, NT, CN>), dim3((unsigned)n_wg), dim3(NT), lds, c->stream,
                        (const uint2*)c->stat_l.p, (const uint16_t*)c->stat_r.p, (uint32_t*)c->C.p, W, H, WP, r, yband,
-                       (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0, ntx, nbands, by_xcd ? nb : -nb);
+                       (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0, ntx, nbands, by_xcd ? nb : -nb,
+                       geo_col0(W, p), W1, p.min_disparity);
     if (H > 1)
         hipLaunchKernelGGL(svk::k_cost_col0, dim3(H - 1, nb), dim3(128), 0, c->stream, (uint32_t*)c->C.p, W1, H, D / 2,
                            (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0);
@@ -434,7 +446,7 @@ void launch_wta_n(sv_ctx* c, int nb) {
     const size_t npx = (size_t)c->W * c->H;
     const dim3 grid((unsigned)((npx * 16 + 255) / 256), nb), block(256);
     hipLaunchKernelGGL((svk::k_wta<N>), grid, block, 0, c->stream, (const uint32_t*)c->S.p, (uint2*)c->rec.p, c->W, c->H,
-                       c->prm.uniqueness_ratio);
+                       c->prm.uniqueness_ratio, geo_col0(c->W, c->prm), geo_w1(c->W, c->prm), c->prm.min_disparity);
 }
 void launch_wta(sv_ctx* c, int nb) {
     switch (c->prm.num_disparities / 32) {
@@ -454,7 +466,7 @@ void launch_wta(sv_ctx* c, int nb) {
 template <int N, int CW>
 int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     constexpr int ROWS = 4 * CW, NTHR = (CW + 1) * 64;
-    const int D = c->prm.num_disparities, W1 = c->W - D, H = c->H;
+    const int D = c->prm.num_disparities, W1 = geo_w1(c->W, c->prm), H = c->H;
     const int n_bands = (H + ROWS - 1) / ROWS;
     constexpr size_t lds = svk::sweep_lds_bytes<N, CW>();
     int per_cu = (int)((160 * 1024) / lds);
@@ -495,6 +507,7 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     a.error = c->sw_error;
     a.sink = (uint32_t*)c->sw_sink.p;
     a.W1 = W1; a.H = H; a.W = c->W;
+    a.col0 = geo_col0(c->W, c->prm); a.min_disp = c->prm.min_disparity;
     a.P1P1 = (uint32_t)c->prm.P1 * 0x10001u;
     a.P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
     a.uniq = c->prm.uniqueness_ratio;
@@ -544,7 +557,7 @@ int sweep_pipes(const sv_ctx* c, int cw) {
 int sweep_cw_for(const sv_ctx* c, int nb) {
     if (c->prm.num_disparities > 128) return 7;
     if (c->sweep_cw) return c->sweep_cw;
-    const int W1 = c->W - c->prm.num_disparities;
+    const int W1 = geo_w1(c->W, c->prm);
     auto cost = [&](int cw, double stream, double fill) {
         const int rows = 4 * cw, bands = (c->H + rows - 1) / rows, pipes = sweep_pipes(c, cw);
         return (double)((nb + pipes - 1) / pipes) * W1 * stream + (double)(bands - 1) * (2 * rows + 2) * fill;
@@ -567,14 +580,15 @@ int check_sweep_error(sv_ctx* c) {
 // cv::filterSpeckles on nb dense-packed frames, in place.  lab / cnt: one int per pixel each (labels are
 // pixel indices within the frame, so a frame must stay below 2^31 pixels; frames are a grid dimension).
 int speckle_launch(sv_ctx* c, int16_t* img, int* lab, int* cnt, int W, int H, int max_size, int max_diff, int nb, hipStream_t st) {
+    const int new_val = geo_inv(c->prm);   // cv::filterSpeckles(disp, (minDisparity - 1) * 16, ...) inside cv::StereoSGBM::compute
     if ((size_t)W * H >= ((size_t)1 << 31)) return fail(c, SV_ERR_UNSUPPORTED, "speckle filter: frame of %dx%d pixels exceeds 2^31 labels", W, H);
     if (nb < 1 || nb > 65535) return fail(c, SV_ERR_INVALID_ARG, "speckle filter: %d frames per call (1..65535)", nb);
     const int n = W * H;
     const dim3 b(256), g1((n + 255) / 256, nb), g2((W + 255) / 256, H, nb);
     hipLaunchKernelGGL(svk::k_speckle_init, g1, b, 0, st, lab, cnt, n);
-    hipLaunchKernelGGL(svk::k_speckle_merge, g2, b, 0, st, img, lab, W, H, SV_INVALID_DISP_SCALED, max_diff);
-    hipLaunchKernelGGL(svk::k_speckle_count, dim3((n + 1023) / 1024, nb), dim3(1024), 0, st, img, lab, cnt, n, SV_INVALID_DISP_SCALED);
-    hipLaunchKernelGGL(svk::k_speckle_apply, g1, b, 0, st, img, lab, cnt, n, SV_INVALID_DISP_SCALED, max_size);
+    hipLaunchKernelGGL(svk::k_speckle_merge, g2, b, 0, st, img, lab, W, H, new_val, max_diff);
+    hipLaunchKernelGGL(svk::k_speckle_count, dim3((n + 1023) / 1024, nb), dim3(1024), 0, st, img, lab, cnt, n, new_val);
+    hipLaunchKernelGGL(svk::k_speckle_apply, g1, b, 0, st, img, lab, cnt, n, new_val, max_size);
     HIPCHK(c, hipGetLastError());
     return SV_OK;
 }
@@ -701,7 +715,8 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
     // (one wave per SIMD or less), so the fusion only pays once the batch fills the chip.
     // Measured crossover at 640x480 D=128: 6 frames x 512 chains; scaled by the chain count so that
     // one 1920x1080 frame (1664 chains per launch) counts as what it is.
-    const bool fuse = !c->debug && (c->force_fuse || (long)nb * (W - D) >= (long)c->fuse_wta_min_batch * 512);
+    const int W1 = geo_w1(W, p), col0 = geo_col0(W, p), colN = geo_colN(W, p);
+    const bool fuse = !c->debug && (c->force_fuse || (long)nb * W1 >= (long)c->fuse_wta_min_batch * 512);
     mark();
     // 1. prefilter + BT statistics
     {
@@ -756,7 +771,7 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         }
         // few frames: all remaining paths at once, each into its own volume, then sum + WTA
         const int n_rest = __builtin_popcount(rest);
-        const long waves_per_launch = (long)nb * ((W - D > H ? W - D : H) + 3) / 4;
+        const long waves_per_launch = (long)nb * ((W1 > H ? W1 : H) + 3) / 4;
         const bool fan = !c->debug && !c->force_fuse && first && n_rest >= 2 && c->fanout_mode >= 0 &&
                          (c->fanout_mode > 0 || waves_per_launch <= 4L * c->n_cu);
         if (fan) {
@@ -800,14 +815,14 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
                                 tail_wgs >= 2L * c->n_cu;
         if (fused_tail) {
             hipLaunchKernelGGL(svk::k_lr_median, dim3((H + svk::LRM_ROWS - 1) / svk::LRM_ROWS, nb), dim3(256), lds_fused, c->stream,
-                               (const uint2*)c->rec.p, disp16, W, H, D, thr, (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
+                               (const uint2*)c->rec.p, disp16, W, H, col0, colN, p.min_disparity, thr, (p.flags & SV_FLAG_MEDIAN_REPLICATE) ? 1 : 0);
         } else {
             if ((size_t)W * 4 > 48 * 1024 && !c->attr_lrcheck) {
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&svk::k_lrcheck), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 c->attr_lrcheck = true;
             }
             hipLaunchKernelGGL(svk::k_lrcheck, dim3(H, nb), dim3(256), (size_t)W * 4, c->stream, (const uint2*)c->rec.p,
-                               (int16_t*)c->disp_lr.p, W, D, thr);
+                               (int16_t*)c->disp_lr.p, W, col0, colN, p.min_disparity, thr);
             const int16_t* cur = (const int16_t*)c->disp_lr.p;
             if (!(p.flags & SV_FLAG_NO_MEDIAN)) {
                 hipLaunchKernelGGL(svk::k_median3, dim3((W + 255) / 256, H, nb), dim3(256), 0, c->stream, cur, disp16, W, H,
@@ -946,7 +961,7 @@ int sv_set_params(sv_ctx* c, const sv_params* params) {
     if (rc) return rc;
     DevGuard g(c->device);
     if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
-    const bool regeom = params->num_disparities != c->prm.num_disparities ||
+    const bool regeom = params->num_disparities != c->prm.num_disparities || params->min_disparity != c->prm.min_disparity ||
                         ((params->flags ^ c->prm.flags) & SV_FLAG_COST_RGB);  // statistics per colour plane
     if (regeom) HIPCHK(c, hipStreamSynchronize(c->stream));
     const sv_params old = c->prm;
@@ -1764,7 +1779,7 @@ int sv_set_debug(sv_ctx* c, int enable) {
 int sv_debug_read_volume_host(sv_ctx* c, int which, int16_t* vol, size_t n_elems) {
     if (!c) return SV_ERR_INVALID_ARG;
     if (which == 1 && !c->debug) return fail(c, SV_ERR_INVALID_ARG, "S is only materialised in debug mode (sv_set_debug)");
-    const size_t nvol = (size_t)(c->W - c->prm.num_disparities) * c->H * c->prm.num_disparities;
+    const size_t nvol = (size_t)geo_w1(c->W, c->prm) * c->H * c->prm.num_disparities;
     if (!vol || n_elems != nvol || which < 0 || which > 1) return fail(c, SV_ERR_INVALID_ARG, "bad volume request");
     DevGuard g(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1784,9 +1799,11 @@ int sv_debug_read_plane_host(sv_ctx* c, int which, int16_t* plane) {
     }
     // one int16 field of the 8-byte WTA records; columns [0, D) are never written by the fused path
     HIPCHK(c, hipMemcpy2D(plane, 2, (const char*)c->rec.p + 2 * which, 8, 2, W * H, hipMemcpyDeviceToHost));
-    static const int16_t inval[3] = {SV_INVALID_DISP_SCALED, -1, 32767};
+    const int16_t inval[3] = {(int16_t)geo_inv(c->prm), -1, 32767};
+    const int col0 = geo_col0(c->W, c->prm), colN = geo_colN(c->W, c->prm);
     for (size_t y = 0; y < H; y++)
-        for (int x = 0; x < c->prm.num_disparities; x++) plane[y * W + x] = inval[which];
+        for (int x = 0; x < (int)W; x++)
+            if (x < col0 || x >= colN) plane[y * W + x] = inval[which];
     return SV_OK;
 }
 
@@ -1850,7 +1867,7 @@ int sv_get_aggregation_timings(sv_ctx* c, float* ms, int n, int* n_launches) {
 int64_t sv_algorithmic_bytes(const sv_ctx* c, int which) {
     if (!c) return -1;
     const int64_t W = c->W, H = c->H, D = c->prm.num_disparities;
-    const int64_t V = (W - D) * H * D * 2;
+    const int64_t V = (int64_t)geo_w1(c->W, c->prm) * H * D * 2;
     int64_t P = 0;
     for (int i = 0; i < 8; i++) P += (c->prm.path_mask >> i) & 1;
     switch (which) {

@@ -335,11 +335,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int N, int NT, int CN>
 __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
                                                uint32_t* __restrict__ C, int W, int H, int WP, int radius, int yband,
-                                               uint32_t P2P2, int tail_p2, int ntx, int nbands, int nframes) {
+                                               uint32_t P2P2, int tail_p2, int ntx, int nbands, int nframes, int col0, int W1,
+                                               int min_disp) {
     constexpr int cn = CN;  // colour planes summed into the cost (1 = gray, 3 = RGB)
     extern __shared__ __align__(16) uint32_t c2_lds[];
-    constexpr int D = 32 * N, D2 = 16 * N, NCOL = NT / 16;
-    const int W1 = W - D, tid = threadIdx.x, j = tid >> 4, q = tid & 15;
+    constexpr int D2 = 16 * N, NCOL = NT / 16;
+    // col0 = first computable column, W1 = their number, min_disp = minDisparity (EXT, cv::StereoSGBM): cost index d
+    // pairs left x with right x - d - min_disp; with min_disp = 0 (the CUDA back-end) col0 = D, W1 = W - D
+    const int tid = threadIdx.x, j = tid >> 4, q = tid & 15;
     const int TX = NCOL - 2 * radius, ringn = 2 * radius + 2;
     uint32_t* const pix = c2_lds;                      // [2][NCOL][D2]
     uint32_t* const ring = pix + 2 * NCOL * D2;        // [ringn][TX][D2]
@@ -359,8 +362,8 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)fr * cn * 6 * H * WP);
     C += (size_t)fr * H * W1 * D2;
     // BT item of this thread: tile column j (clamped into the computable band), disparities 2N*q ..
-    const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + D;
-    const int e = (W - 1 - xj) + 2 * N * q;            // reversed index of x - d for the first disparity
+    const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + col0;
+    const int e = (W - 1 - xj) + min_disp + 2 * N * q;  // reversed index of x - d - min_disp for the first disparity
     const int cpy = e & 1;
     const size_t plane = (size_t)H * WP / 2;           // dwords per plane copy
     const uint32_t* rbase = rp32 + (size_t)cpy * plane + (size_t)((e - cpy) >> 1);
@@ -570,8 +573,10 @@ __device__ __forceinline__ WtaPart wta_reduce(const uint32_t (&s)[N], int q, Uni
 
 // The per-pixel arithmetic on the reduced words (lane-local: k_sweep runs it once per 16 pixels,
 // each lane finishing a different pixel).  D = number of disparities.
+// min_disp (EXT, cv::StereoSGBM minDisparity): the stored disparity is (best + min_disp) * 16 + sub-pixel, "none" is
+// (min_disp - 1) * 16; the raw field stays the cost index (-1 = none).
 template <int D>
-__device__ __forceinline__ uint2 wta_finish(WtaPart w, UniqK uq) {
+__device__ __forceinline__ uint2 wta_finish(WtaPart w, UniqK uq, int min_disp = 0) {
     const int minS = (int)(w.key >> 16), best = (int)(w.key & 0xFFu);
     const uint32_t cnt = (w.key >> 8) & 0xFFu;
     const uint32_t T = wta_threshold((uint32_t)minS, uq);
@@ -590,13 +595,13 @@ __device__ __forceinline__ uint2 wta_finish(WtaPart w, UniqK uq) {
     const uint32_t qf = (uint32_t)((float)(2u * mag + 1u) * __builtin_amdgcn_rcpf((float)(4 * den)));
     const int sub = inner ? (int)((qf ^ (uint32_t)sgn) - (uint32_t)sgn) : 0;
     const bool ok = minS < 32767 && !bad;  // minS == 32767: every S saturated, no minimum
-    const int dv = ok ? best * 16 + sub : -16, rw = ok ? best : -1;
+    const int dv = ok ? (best + min_disp) * 16 + sub : (min_disp - 1) * 16, rw = ok ? best : -1;
     return make_uint2(((uint32_t)dv & 0xFFFFu) | ((uint32_t)rw << 16), (uint32_t)minS);
 }
 
 template <int N>
-__device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK uq) {
-    return wta_finish<32 * N>(wta_reduce<N>(s, q, uq), uq);
+__device__ __forceinline__ uint2 wta_record(const uint32_t (&s)[N], int q, UniqK uq, int min_disp = 0) {
+    return wta_finish<32 * N>(wta_reduce<N>(s, q, uq), uq, min_disp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,9 +629,9 @@ struct AggBatch {
 // only the 8-byte WTA record leaves the kernel (saves one volume write and one volume read).
 template <int N, bool VERT, int MODE, int U>
 __device__ __forceinline__ void agg_body(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, int W1, int H, int dx, int dy,
-                                         uint32_t P1P1, uint32_t P2P2, uint2* __restrict__ rec, int uniq) {
-    constexpr bool FIRST = (MODE & 1) != 0, LAST = (MODE & 2) != 0;
-    const int W = W1 + 32 * N;
+                                         uint32_t P1P1, uint32_t P2P2, uint2* __restrict__ rec, int uniq, int W = 0, int col0 = 0,
+                                         int min_disp = 0) {
+    constexpr bool FIRST = (MODE & 1) != 0, LAST = (MODE & 2) != 0;  // W, col0, min_disp: only used by LAST (record index, WTA)
     const int q = threadIdx.x & 15;
     const int nchains = VERT ? W1 : H, nsteps = VERT ? H : W1;
     // Chains past the end repeat the last chain: same loads, same arithmetic, same stores from
@@ -653,7 +658,7 @@ __device__ __forceinline__ void agg_body(const uint32_t* __restrict__ C, uint32_
             // clamped: a prefetch that runs past the last step reads a valid (unused) pixel
             const int cy = min(max(ly, 0), H - 1), cx = min(max(lx, 0), W1 - 1);
             b.off[j] = ((size_t)cy * W1 + cx) * pxN + laneoff;
-            if (LAST) b.px[j] = (uint32_t)(cy * W + cx + 32 * N);
+            if (LAST) b.px[j] = (uint32_t)(cy * W + cx + col0);
             load_regs<N>(C + b.off[j], b.c[j]);
             if (!FIRST) load_regs<N>(S + b.off[j], b.s[j]);
             if (VERT) {
@@ -704,7 +709,7 @@ __device__ __forceinline__ void agg_body(const uint32_t* __restrict__ C, uint32_
         mn = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // both halves = lane minimum
         mn = row16_min_u32(mn);
         dd = mn + P2P2;  // halves cannot carry: min + P2 < 65536
-        if (LAST) rec[px] = wta_record<N>(snew, q, uqk);  // all 16 lanes store the same record
+        if (LAST) rec[px] = wta_record<N>(snew, q, uqk, min_disp);  // all 16 lanes store the same record
         else store_regs<N>(S + off, snew);
     };
 
@@ -749,14 +754,15 @@ __device__ __forceinline__ void agg_body(const uint32_t* __restrict__ C, uint32_
 #pragma unroll
             for (int k = 0; k < N; k++) s[k] = 0;
         }
-        step(c, s, off, (uint32_t)(y * W + x + 32 * N), fresh);
+        step(c, s, off, (uint32_t)(y * W + x + col0), fresh);
     }
 }
 
 template <int N, bool VERT, int MODE, int U>
 __global__ __launch_bounds__(64) void k_agg(const uint32_t* __restrict__ C, uint32_t* __restrict__ S, int W1, int H, int dx,
-                                             int dy, uint32_t P1P1, uint32_t P2P2, uint2* __restrict__ rec, int uniq) {
-    agg_body<N, VERT, MODE, U>(C, S, W1, H, dx, dy, P1P1, P2P2, rec, uniq);
+                                             int dy, uint32_t P1P1, uint32_t P2P2, uint2* __restrict__ rec, int uniq, int W, int col0,
+                                             int min_disp) {
+    agg_body<N, VERT, MODE, U>(C, S, W1, H, dx, dy, P1P1, P2P2, rec, uniq, W, col0, min_disp);
 }
 
 // All paths of a small batch in ONE launch: blockIdx.z picks the path, every path writes its own L
@@ -788,19 +794,19 @@ __global__ __launch_bounds__(64) void k_agg_paths(const uint32_t* __restrict__ C
 // raw = -1 marks "no disparity" (reference: INVALID_DISP_SCALED in d_raw_disp, :642).
 // ---------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, uint2* __restrict__ rec, int W, int H, int uniq) {
-    const int D = 32 * N, W1 = W - D;
+__global__ __launch_bounds__(256) void k_wta(const uint32_t* __restrict__ S, uint2* __restrict__ rec, int W, int H, int uniq, int col0,
+                                              int W1, int min_disp) {
     const int q = threadIdx.x & 15;
     const size_t pid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const size_t npx = (size_t)W * H;
     const size_t p = min(pid, npx - 1);  // surplus groups repeat the last pixel (same value, same wave)
     const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
-    const int xl = max(x - D, 0);
+    const int xl = min(max(x - col0, 0), W1 - 1);
     S += (size_t)blockIdx.y * H * W1 * 16 * N;
     uint32_t s[N];
     load_regs<N>(S + ((size_t)y * W1 + xl) * 16 * N + q * N, s);
-    uint2 r = wta_record<N>(s, q, make_uniq(uniq));
-    if (x < D) r = make_uint2(0xFFFFFFF0u, 32767u);  // {-16, -1, 32767}
+    uint2 r = wta_record<N>(s, q, make_uniq(uniq), min_disp);
+    if (x < col0 || x >= col0 + W1) r = make_uint2(0xFFFF0000u | (uint32_t)(((min_disp - 1) * 16) & 0xFFFF), 32767u);  // {invalid, -1, 32767}
     rec[(size_t)blockIdx.y * npx + p] = r;
 }
 
@@ -812,8 +818,8 @@ struct PathBufs {
     int n;
 };
 template <int N>
-__global__ __launch_bounds__(256) void k_sum_wta(PathBufs pb, uint2* __restrict__ rec, int W, int H, int uniq) {
-    const int D = 32 * N, W1 = W - D;
+__global__ __launch_bounds__(256) void k_sum_wta(PathBufs pb, uint2* __restrict__ rec, int W, int H, int uniq, int col0, int W1,
+                                                  int min_disp) {
     const int q = threadIdx.x & 15;
     const size_t pid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const size_t npx = (size_t)W1 * H;
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(256) void k_sum_wta(PathBufs pb, uint2* __restrict_
 #pragma unroll
         for (int k = 0; k < N; k++) acc[k] = pk_add_sat15(acc[k], v[k]);
     }
-    rec[((size_t)blockIdx.y * H + y) * W + xl + D] = wta_record<N>(acc, q, make_uniq(uniq));
+    rec[((size_t)blockIdx.y * H + y) * W + xl + col0] = wta_record<N>(acc, q, make_uniq(uniq), min_disp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -836,22 +842,26 @@ __global__ __launch_bounds__(256) void k_sum_wta(PathBufs pb, uint2* __restrict_
 // the larger x); the same winner is the minimum of the packed key (cost << 16 | 0xFFFF - x), so an
 // LDS atomicMin reproduces it without the serial scan.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lrcheck(const uint2* __restrict__ rec, int16_t* __restrict__ out, int W, int D,
-                                                  int thresh) {
+// col0 / colN: the computable columns; min_disp (EXT): the raw field of a record is the cost index, the pixel it
+// matches in the right image is x - index - min_disp, and "none" is (min_disp - 1) * 16.  The disparity the key
+// stands for, x_src - x2, is the true one (index + min_disp), which is what cv::StereoSGBM keeps in disp2.
+__global__ __launch_bounds__(256) void k_lrcheck(const uint2* __restrict__ rec, int16_t* __restrict__ out, int W, int col0, int colN,
+                                                  int min_disp, int thresh) {
     extern __shared__ uint32_t keys[];
     const int y = blockIdx.x + blockIdx.y * gridDim.x;  // gridDim.x = H, blockIdx.y = frame
-    const uint2* rc = rec + (size_t)y * W;  // {disp16 | raw << 16, minS}; columns [0, D) are never read
+    const uint2* rc = rec + (size_t)y * W;  // {disp16 | raw << 16, minS}; columns outside [col0, colN) are never read
+    const int inv = (min_disp - 1) * 16;
     for (int x = threadIdx.x; x < W; x += blockDim.x) keys[x] = 0xFFFFFFFFu;
     __syncthreads();
-    for (int x = D + threadIdx.x; x < W; x += blockDim.x) {
+    for (int x = col0 + threadIdx.x; x < colN; x += blockDim.x) {
         const uint2 r = rc[x];
         const int d = (int)(int16_t)(r.x >> 16);
-        if (d >= 0) atomicMin(&keys[x - d], (r.y << 16) | (uint32_t)(0xFFFF - x));
+        if (d >= 0) atomicMin(&keys[x - d - min_disp], (r.y << 16) | (uint32_t)(0xFFFF - x));
     }
     __syncthreads();
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        int d1 = x >= D ? (int)(int16_t)(rc[x].x & 0xFFFFu) : -16;
-        if (d1 != -16) {
+        int d1 = (x >= col0 && x < colN) ? (int)(int16_t)(rc[x].x & 0xFFFFu) : inv;
+        if (d1 != inv) {
             int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
             int _x = x - _d, x_ = x - d_;
             bool f1 = false, f2 = false;
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(256) void k_lrcheck(const uint2* __restrict__ rec, 
                 uint32_t k = keys[x_];
                 if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - x_; f2 = abs(d2 - d_) > thresh; }
             }
-            if (f1 && f2) d1 = -16;
+            if (f1 && f2) d1 = inv;
         }
         out[(size_t)y * W + x] = (int16_t)d1;
     }
@@ -877,12 +887,13 @@ __global__ __launch_bounds__(256) void k_lrcheck(const uint2* __restrict__ rec, 
 // ---------------------------------------------------------------------------------------------
 constexpr int LRM_ROWS = 16;
 __device__ __forceinline__ void cswap16(int& a, int& b) { int t = min(a, b); b = max(a, b); a = t; }
-__global__ __launch_bounds__(256) void k_lr_median(const uint2* __restrict__ rec, int16_t* __restrict__ out, int W, int H, int D,
-                                                    int thresh, int replicate) {
+__global__ __launch_bounds__(256) void k_lr_median(const uint2* __restrict__ rec, int16_t* __restrict__ out, int W, int H, int col0,
+                                                    int colN, int min_disp, int thresh, int replicate) {
     extern __shared__ uint32_t lrm_lds[];
     uint32_t* keys = lrm_lds;                                       // [W]
     int16_t* rows = reinterpret_cast<int16_t*>(lrm_lds + W);        // [3][W]: checked rows yl-2, yl-1, yl (slot = (yl + 3) % 3)
     const int ya = blockIdx.x * LRM_ROWS, yb = min(ya + LRM_ROWS, H);
+    const int inv = (min_disp - 1) * 16;
     rec += (size_t)blockIdx.y * W * H;
     out += (size_t)blockIdx.y * W * H;
     for (int yl = ya - 1; yl <= yb; yl++) {
@@ -891,15 +902,15 @@ __global__ __launch_bounds__(256) void k_lr_median(const uint2* __restrict__ rec
         int16_t* lr = rows + (size_t)((yl + 3) % 3) * W;
         for (int x = threadIdx.x; x < W; x += blockDim.x) keys[x] = 0xFFFFFFFFu;
         __syncthreads();
-        for (int x = D + threadIdx.x; x < W; x += blockDim.x) {
+        for (int x = col0 + threadIdx.x; x < colN; x += blockDim.x) {
             const uint2 r = rc[x];
             const int d = (int)(int16_t)(r.x >> 16);
-            if (d >= 0) atomicMin(&keys[x - d], (r.y << 16) | (uint32_t)(0xFFFF - x));
+            if (d >= 0) atomicMin(&keys[x - d - min_disp], (r.y << 16) | (uint32_t)(0xFFFF - x));
         }
         __syncthreads();
         for (int x = threadIdx.x; x < W; x += blockDim.x) {
-            int d1 = x >= D ? (int)(int16_t)(rc[x].x & 0xFFFFu) : -16;
-            if (d1 != -16) {
+            int d1 = (x >= col0 && x < colN) ? (int)(int16_t)(rc[x].x & 0xFFFFu) : inv;
+            if (d1 != inv) {
                 int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
                 int _x = x - _d, x_ = x - d_;
                 bool f1 = false, f2 = false;
@@ -911,7 +922,7 @@ __global__ __launch_bounds__(256) void k_lr_median(const uint2* __restrict__ rec
                     uint32_t k = keys[x_];
                     if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - x_; f2 = abs(d2 - d_) > thresh; }
                 }
-                if (f1 && f2) d1 = -16;
+                if (f1 && f2) d1 = inv;
             }
             lr[x] = (int16_t)d1;
         }

@@ -52,6 +52,7 @@ struct SweepArgs {
     unsigned int* error;           // host-visible: set when a bounded wait ran out
     uint32_t* sink;                // [gridDim.x * blockDim.x * 4] u32: target of the stores of inactive steps
     int W1, H, W;
+    int col0, min_disp;            // first computable column; minDisparity (EXT): stored disparity = (index + min_disp) * 16 + sub-pixel
     uint32_t P1P1, P2P2;
     int uniq;
     int n_frames, n_groups, n_bands;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     const uint32_t big0 = q == 0 ? 0x7FFF7FFFu : 0u, big15 = q == 15 ? 0x7FFF7FFFu : 0u;  // see sweep_path
     uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH], recq[SW_DEPTH];
     uint32_t lrbase = 0;                             // index of frame lfi's first WTA record
-    const uint32_t rowrec = (uint32_t)yp * a.W + 32 * N, frame_px = (uint32_t)H * a.W;
+    const uint32_t rowrec = (uint32_t)yp * a.W + a.col0, frame_px = (uint32_t)H * a.W;
     bool actq[SW_DEPTH];
 
     auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N], uint32_t& off, uint32_t& rq, bool& act) {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     stash.nb = mine ? w.nb : stash.nb;
                     stash_rq = mine ? (active ? recq[j] : 0xFFFFFFFFu) : stash_rq;
                     if (j == SW_DEPTH - 1 && ((tau + j) & 15) == 15) {
-                        if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk);
+                        if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk, a.min_disp);
                         stash_rq = 0xFFFFFFFFu;
                     }
                 } else {
@@ -307,7 +308,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
             }
         }
         // pixels kept since the last 16-step boundary
-        if (SECOND && stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk);
+        if (SECOND && stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk, a.min_disp);
         SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
     } else {
         bool aborted = false;

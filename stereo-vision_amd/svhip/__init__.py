@@ -421,8 +421,8 @@ class Matcher:
         self._chk(self._L.sv_set_debug(self._h, int(on)))
 
     def debug_volume(self, which):
-        D = self.params.num_disparities
-        out = np.empty((self.H, self.W - D, D), np.int16)
+        D, minD = self.params.num_disparities, self.params.min_disparity
+        out = np.empty((self.H, (self.W + min(minD, 0)) - max(minD + D, 0), D), np.int16)
         self._chk(self._L.sv_debug_read_volume_host(self._h, which, _ptr(out), out.size))
         return out
 
