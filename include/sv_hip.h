@@ -431,6 +431,26 @@ int64_t sv_algorithmic_bytes(const sv_ctx* ctx, int which);
 const char* sv_last_error(const sv_ctx* ctx);
 const char* sv_version(void);
 
+/* In-process multi-device dispatch (BASELINE.json configs[4]): one context, one stream and - inside
+ * sv_pool_compute_gray_host - one host thread per entry of `devices` (a device may be listed more than once: several
+ * contexts share it).  Stereo pairs are independent: the n_frames pairs of a call are cut into chunks of `batch`
+ * consecutive pairs and chunk k goes to context k mod n_contexts (sv_pool_plan states the rule and is what the call
+ * follows); each context runs its chunks through sv_submit_gray_batch_host / sv_wait_batch_host with two chunks in
+ * flight, so uploads, kernels and downloads overlap per device.  No collective and no traffic between devices; every
+ * pair has its own output pointer, so results are in submission order by construction.  The call returns when every
+ * pair is done (or with the first error; sv_pool_last_error).  Buffers as for sv_submit_gray_batch_host (pinned
+ * memory makes the copies asynchronous).  The reference handles one pair per updateModule() on one GPU
+ * (DispModule.cpp:661-814, bova_sgm.cu:7-30); no counterpart there.                                           */
+typedef struct sv_pool sv_pool;
+int sv_pool_create(sv_pool** out, const int* devices, int n_devices, int width, int height, const sv_params* params, int batch);
+int sv_pool_destroy(sv_pool* pool);
+int sv_pool_size(const sv_pool* pool);
+int sv_pool_plan(int n_frames, int n_contexts, int batch, int frame, int* context_index, int* chunk_index);
+int sv_pool_compute_gray_host(sv_pool* pool, int n_frames, const uint8_t* const* left_host, size_t left_stride,
+                              const uint8_t* const* right_host, size_t right_stride, int16_t* const* disp16_host,
+                              size_t disp_stride);
+const char* sv_pool_last_error(const sv_pool* pool);
+
 #ifdef __cplusplus
 }
 #endif

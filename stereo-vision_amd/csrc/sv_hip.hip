@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "sv_kernels.hip.h"
@@ -1878,6 +1879,118 @@ int64_t sv_algorithmic_bytes(const sv_ctx* c, int which) {
         case 4: return (3 * P + 2) * V + 16 * W * H;
         default: return -1;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// In-process multi-device dispatch: stereo pairs are independent, so a host that
+// serves many camera streams deals chunks of pairs to one context per device, one host thread and
+// one stream per context, no collective, no traffic between devices; every pair has its own
+// output pointer, so results land in submission order by construction.
+// ---------------------------------------------------------------------------------------------
+struct sv_pool {
+    std::vector<sv_ctx*> ctx;
+    std::vector<hipStream_t> stream;
+    int W = 0, H = 0, batch = 0;
+    char err[512] = {0};
+};
+
+int sv_pool_plan(int n_frames, int n_contexts, int batch, int frame, int* context_index, int* chunk_index) {
+    if (n_frames < 0 || n_contexts < 1 || batch < 1 || frame < 0 || frame >= n_frames || !context_index || !chunk_index)
+        return SV_ERR_INVALID_ARG;
+    const int chunk = frame / batch;      // chunks of `batch` consecutive frames ...
+    *chunk_index = chunk;
+    *context_index = chunk % n_contexts;  // ... dealt round-robin to the contexts
+    return SV_OK;
+}
+
+const char* sv_pool_last_error(const sv_pool* p) { return p ? p->err : k_noctx; }
+
+int sv_pool_destroy(sv_pool* p) {
+    if (!p) return SV_ERR_INVALID_ARG;
+    for (size_t i = 0; i < p->ctx.size(); i++) {
+        const int dev = p->ctx[i] ? p->ctx[i]->device : -1;
+        if (p->ctx[i]) sv_destroy(p->ctx[i]);
+        if (p->stream[i] && dev >= 0) {
+            DevGuard g(dev);
+            (void)hipStreamDestroy(p->stream[i]);
+        }
+    }
+    delete p;
+    return SV_OK;
+}
+
+int sv_pool_create(sv_pool** out, const int* devices, int n_devices, int width, int height, const sv_params* params, int batch) {
+    if (!out) return SV_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64 || batch < 1) return SV_ERR_INVALID_ARG;
+    sv_pool* p = new (std::nothrow) sv_pool();
+    if (!p) return SV_ERR_NOMEM;
+    *out = p;  // returned even on failure: sv_pool_last_error, then sv_pool_destroy
+    p->W = width; p->H = height; p->batch = batch;
+    p->ctx.assign(n_devices, nullptr);
+    p->stream.assign(n_devices, nullptr);
+    for (int i = 0; i < n_devices; i++) {
+        int rc = sv_create(&p->ctx[i], devices[i], width, height, params);
+        if (rc == SV_OK) rc = sv_set_batch(p->ctx[i], batch);
+        if (rc == SV_OK) {
+            DevGuard g(devices[i]);
+            // a stream of its own: two contexts on one device (or the caller's other work) overlap instead of queueing on stream 0
+            if (hipStreamCreateWithFlags(&p->stream[i], hipStreamNonBlocking) != hipSuccess) rc = SV_ERR_HIP;
+            else rc = sv_set_stream(p->ctx[i], p->stream[i]);
+        }
+        if (rc != SV_OK) {
+            snprintf(p->err, sizeof(p->err), "context %d (device %d): %s", i, devices[i], p->ctx[i] ? sv_last_error(p->ctx[i]) : "sv_create failed");
+            return rc;
+        }
+    }
+    return SV_OK;
+}
+
+int sv_pool_size(const sv_pool* p) { return p ? (int)p->ctx.size() : SV_ERR_INVALID_ARG; }
+
+int sv_pool_compute_gray_host(sv_pool* p, int n_frames, const uint8_t* const* left, size_t ls, const uint8_t* const* right, size_t rs,
+                              int16_t* const* disp16, size_t ds) {
+    if (!p) return SV_ERR_INVALID_ARG;
+    if (n_frames < 0 || (n_frames > 0 && (!left || !right || !disp16))) { snprintf(p->err, sizeof(p->err), "bad argument"); return SV_ERR_INVALID_ARG; }
+    const int n_ctx = (int)p->ctx.size(), batch = p->batch;
+    const int n_chunks = (n_frames + batch - 1) / batch;
+    std::vector<int> rcs(n_ctx, SV_OK);
+    auto work = [&](int k) {
+        sv_ctx* c = p->ctx[k];
+        int tickets[SV_BATCH_SLOTS];
+        int in_flight = 0, head = 0;   // ring of tickets, oldest at head
+        for (int chunk = k; chunk < n_chunks && rcs[k] == SV_OK; chunk += n_ctx) {   // sv_pool_plan: chunk -> context chunk % n_ctx
+            if (in_flight == SV_BATCH_SLOTS) {
+                rcs[k] = sv_wait_batch_host(c, tickets[head]);
+                head = (head + 1) % SV_BATCH_SLOTS;
+                in_flight--;
+                if (rcs[k] != SV_OK) break;
+            }
+            const int f0 = chunk * batch, n = std::min(batch, n_frames - f0);
+            int t = -1;
+            rcs[k] = sv_submit_gray_batch_host(c, n, left + f0, ls, right + f0, rs, disp16 + f0, ds, &t);
+            if (rcs[k] != SV_OK) break;
+            tickets[(head + in_flight) % SV_BATCH_SLOTS] = t;
+            in_flight++;
+        }
+        while (in_flight > 0) {   // also after an error: nothing of this context may stay in flight when the call returns
+            const int rc = sv_wait_batch_host(c, tickets[head]);
+            if (rcs[k] == SV_OK) rcs[k] = rc;
+            head = (head + 1) % SV_BATCH_SLOTS;
+            in_flight--;
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < n_ctx; k++) threads.emplace_back(work, k);
+    work(0);   // the calling thread serves context 0
+    for (auto& t : threads) t.join();
+    for (int k = 0; k < n_ctx; k++)
+        if (rcs[k] != SV_OK) {
+            snprintf(p->err, sizeof(p->err), "context %d (device %d): %s", k, p->ctx[k]->device, sv_last_error(p->ctx[k]));
+            return rcs[k];
+        }
+    return SV_OK;
 }
 
 }  // extern "C"

@@ -33,7 +33,8 @@ EXPORTS = (
     "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_filter_blf_joint_dev", "sv_filter_blf_joint_host", "sv_compute_rgb_batch_dev", "sv_disparity_vis_batch_dev", "sv_depth_batch_dev", "sv_world_image_dev", "sv_world_image_host",
     "sv_synchronize", "sv_last_aggregation", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
-    "sv_algorithmic_bytes", "sv_last_error", "sv_version", "sv_get_aggregation_timings", "sv_filter_speckles_static_dev", "sv_last_sweep_waves", "sv_compute_rgb_vis_host")
+    "sv_algorithmic_bytes", "sv_last_error", "sv_version", "sv_get_aggregation_timings", "sv_filter_speckles_static_dev", "sv_last_sweep_waves", "sv_compute_rgb_vis_host",
+    "sv_pool_create", "sv_pool_destroy", "sv_pool_size", "sv_pool_plan", "sv_pool_compute_gray_host", "sv_pool_last_error")
 STATIC_MAX_PIXELS = 1920 * 1088   # SV_STATIC_MAX_PIXELS
 
 
@@ -133,6 +134,13 @@ def load():
     L.sv_get_aggregation_timings.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]
     L.sv_filter_speckles_static_dev.argtypes = [vp, vp, i32, i32]
     L.sv_last_sweep_waves.argtypes = [vp]
+    L.sv_pool_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), i32, i32, i32, C.POINTER(Params), i32]
+    L.sv_pool_destroy.argtypes = [vp]
+    L.sv_pool_size.argtypes = [vp]
+    L.sv_pool_plan.argtypes = [i32, i32, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sv_pool_compute_gray_host.argtypes = [vp, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, C.POINTER(vp), sz]
+    L.sv_pool_last_error.restype = C.c_char_p
+    L.sv_pool_last_error.argtypes = [vp]
     L.sv_algorithmic_bytes.restype = C.c_int64
     L.sv_algorithmic_bytes.argtypes = [vp, i32]
     _lib = L
@@ -457,6 +465,54 @@ class Matcher:
 
     def gray_from_rgb_dev(self, rgb_t, gray_t):
         self._chk(self._L.sv_gray_from_rgb_dev(self._h, C.c_void_p(rgb_t.data_ptr()), C.c_void_p(gray_t.data_ptr())))
+
+
+def pool_plan(n_frames, n_contexts, batch, frame):
+    """(context index, chunk index) of `frame` under sv_pool's dealing rule (pure function, needs no GPU)."""
+    a, b = C.c_int(), C.c_int()
+    rc = load().sv_pool_plan(n_frames, n_contexts, batch, frame, C.byref(a), C.byref(b))
+    if rc:
+        raise SvError(rc, "sv_pool_plan")
+    return a.value, b.value
+
+
+class Pool:
+    """sv_pool: one context + stream + host thread per entry of `devices`."""
+
+    def __init__(self, devices, width, height, params, batch):
+        self._L = load()
+        self._h = C.c_void_p()
+        self.W, self.H = width, height
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self._L.sv_pool_create(C.byref(self._h), devs, len(devices), width, height, C.byref(params), batch)
+        if rc:
+            msg = self._L.sv_pool_last_error(self._h).decode() if self._h else "sv_pool_create failed"
+            if self._h:
+                self._L.sv_pool_destroy(self._h)
+                self._h = C.c_void_p()
+            raise SvError(rc, msg)
+
+    def compute_gray(self, lefts, rights, outs):
+        """lefts / rights / outs: sequences of numpy arrays (or addresses), one per pair; blocks until all are done."""
+        n = len(lefts)
+        addr = lambda a: a if isinstance(a, int) else a.ctypes.data
+        pl = (C.c_void_p * n)(*[addr(a) for a in lefts])
+        pr = (C.c_void_p * n)(*[addr(a) for a in rights])
+        po = (C.c_void_p * n)(*[addr(a) for a in outs])
+        rc = self._L.sv_pool_compute_gray_host(self._h, n, pl, self.W, pr, self.W, po, 2 * self.W)
+        if rc:
+            raise SvError(rc, self._L.sv_pool_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.sv_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PinnedArray:

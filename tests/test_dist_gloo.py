@@ -1,10 +1,13 @@
-"""world_size-2 gloo test (CPU) of the multi-GPU path: frame sharding, ordered merge of the results
-on rank 0 and the max-over-ranks timing rule.  The per-frame compute here is the CPU oracle (tests
-may use it); on GPUs the same code runs with a Matcher per rank (bench.py)."""
+"""world_size-2 gloo tests of the multi-GPU path: frame sharding, ordered merge of the results on rank 0 and the
+max-over-ranks timing rule.  On the CPU the per-frame compute is the oracle (tests may use it); the GPU variant
+runs the same worker with a svhip.Matcher per rank (both ranks on device 0: the one-GPU box), i.e. the real
+library under the rank / seed / merge logic bench.py --gpus N relies on.  Plus the dealing rule of the
+in-process dispatcher (sv_pool_plan), which needs no device.  No N > 1 hardware run exists."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from svhip import shard
@@ -27,7 +30,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, use_gpu=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, "stereo-vision_amd"), os.path.join(root, "oracle")):
@@ -42,10 +45,14 @@ def _worker(rank, world, port, q):
     frames = [synth.stereo_pair(500 + i, W, H, D)[:2] for i in range(5)]
     p = svref.default_params(D, 8)
     calls = []
+    matcher = None
+    if use_gpu:
+        import svhip
+        matcher = svhip.Matcher(W, H, svhip.default_params(D, 8), device=0)   # every rank its own context (here: on the same GPU)
 
     def compute(l, r):
         calls.append(1)
-        return svref.sgbm(l, r, p)
+        return matcher.compute_gray(l, r) if matcher else svref.sgbm(l, r, p)
 
     res = shard.run_sharded(frames, compute, dist)
     t = shard.max_over_ranks(1.0 + rank, dist)
@@ -55,16 +62,40 @@ def _worker(rank, world, port, q):
         q.put((len(calls), None, t))
     dist.barrier()
     dist.destroy_process_group()
+    if matcher:
+        matcher.close()
 
 
-def test_two_rank_sharding_matches_single_process():
+def test_pool_plan_deals_chunks_round_robin():
+    """sv_pool_plan (pure, no device): chunks of `batch` consecutive frames, chunk k -> context k mod n; every frame is
+    dealt exactly once, a context's frames keep their order, loads differ by at most one chunk."""
+    import svhip
+    for n, nctx, batch in ((0, 2, 4), (1, 3, 8), (37, 2, 8), (64, 8, 4), (100, 3, 7)):
+        seen = {}
+        for f in range(n):
+            k, chunk = svhip.pool_plan(n, nctx, batch, f)
+            assert chunk == f // batch and k == chunk % nctx
+            seen.setdefault(k, []).append(f)
+        assert sorted(sum(seen.values(), [])) == list(range(n))
+        for frames in seen.values():
+            assert frames == sorted(frames)
+        if n:
+            sizes = [len(seen.get(k, [])) for k in range(nctx)]
+            assert max(sizes) - min(sizes) <= batch
+    with pytest.raises(svhip.SvError):
+        svhip.pool_plan(10, 0, 4, 0)
+    with pytest.raises(svhip.SvError):
+        svhip.pool_plan(10, 2, 4, 10)
+
+
+def _run_two_ranks(use_gpu):
     import svref
     from svhip import synth
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, use_gpu)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
@@ -80,3 +111,38 @@ def test_two_rank_sharding_matches_single_process():
     for i in range(5):
         l, r = synth.stereo_pair(500 + i, W, H, D)[:2]
         assert res[i] == svref.sgbm(l, r, prm).tobytes(), "frame %d out of order or wrong" % i
+
+
+def test_two_rank_sharding_matches_single_process():
+    _run_two_ranks(False)
+
+
+@pytest.mark.gpu
+def test_two_rank_sharding_with_the_hip_library(gpu):
+    """The same two-rank run with libsv_hip computing every frame (one context per rank, both on device 0)."""
+    _run_two_ranks(True)
+
+
+@pytest.mark.gpu
+def test_pool_two_contexts_one_device(gpu):
+    """sv_pool with two contexts (here both on device 0), 37 pairs in chunks of 8, every pair in its own buffer: each
+    result lands in its own output buffer, bit-exact against the oracle; then a second, shorter call."""
+    import svhip
+    import svref
+    from concurrent.futures import ThreadPoolExecutor
+    from svhip import synth
+    W, H, D, n = 200, 96, 64, 37
+    pairs = [synth.stereo_pair(1700 + i, W, H, D)[:2] for i in range(n)]
+    outs = [np.full((H, W), 12345, np.int16) for _ in range(n)]
+    pool = svhip.Pool([0, 0], W, H, svhip.default_params(D, 8), 8)
+    pool.compute_gray([p[0] for p in pairs], [p[1] for p in pairs], outs)
+    po = svref.default_params(D, 8)
+    with ThreadPoolExecutor(8) as ex:
+        refs = list(ex.map(lambda p: svref.sgbm(p[0], p[1], po), pairs))
+    for i in range(n):
+        assert np.array_equal(outs[i], refs[i]), "pair %d differs" % i
+    outs2 = [np.zeros((H, W), np.int16) for _ in range(5)]
+    pool.compute_gray([p[0] for p in pairs[10:15]], [p[1] for p in pairs[10:15]], outs2)
+    for i in range(5):
+        assert np.array_equal(outs2[i], refs[10 + i])
+    pool.close()
