@@ -211,8 +211,10 @@ def main():
     if args.config == "c3":
         # full pipeline per frame: remap x2 -> gray x2 -> SGM -> vis -> WLS (16-bit map + vis) -> depth
         rng = np.random.default_rng(seed0)
-        lrgb = torch.from_numpy(np.stack([synth.rgb_from_gray(rng, lefts[i % n_distinct]) for i in range(B)])).cuda()
-        rrgb = torch.from_numpy(np.stack([synth.rgb_from_gray(rng, rights[i % n_distinct]) for i in range(B)])).cuda()
+        lsrc = [synth.rgb_from_gray(rng, lefts[i]) for i in range(n_distinct)]
+        rsrc = [synth.rgb_from_gray(rng, rights[i]) for i in range(n_distinct)]
+        lrgb = torch.from_numpy(np.stack([lsrc[i % n_distinct] for i in range(B)])).cuda()
+        rrgb = torch.from_numpy(np.stack([rsrc[i % n_distinct] for i in range(B)])).cuda()
         cams = [synth.camera(W, H, i) for i in (0, 1)]
         for i in (0, 1):   # the synthetic pairs are already row-aligned: both views get the left camera's model
             m.init_rectify_map(i, *cams[0])

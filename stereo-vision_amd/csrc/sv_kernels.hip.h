@@ -1245,14 +1245,16 @@ __global__ __launch_bounds__(256) void k_wls_store(const float* __restrict__ cur
     else out8[o] = (uint8_t)fminf(fmaxf(r, 0.0f), 255.0f);
 }
 
-// Row solves.  One wave owns 64 rows; the row is walked in 64-column chunks that are moved
-// between HBM/L2 and LDS with coalesced accesses and read by the solving lane along its own LDS
-// row (stride 65 words: conflict-free).  The forward sweep leaves the modified right-hand side in
-// cur and the modified super-diagonal in tmp; the backward sweep walks the chunks in reverse.
-// The solve itself is a serial dependency chain (mul, sub, div per sample), so inside a chunk the
-// lane moves FGS_R samples at a time between LDS and registers: the LDS round trips then overlap
-// the chain instead of sitting on it.
-constexpr int FGS_T = 64, FGS_R = 16;
+// Row solves: one lane per row, the row walked four samples (one 16-byte access) at a time, FGS_PD such groups
+// of loads in flight ahead of the dependent solve chain (mul, sub, div per sample: ~45 cycles each), so the
+// memory latency hides behind the arithmetic.  A wave's 64 lanes touch 64 different rows per access; the eight
+// accesses that share a 128-byte line follow each other closely and are served by L1 / L2 (HBM sees each line
+// once).  (The first form staged 64x64 tiles through LDS with coalesced accesses; its load / solve / store
+// phases ran one after the other and exposed the memory latency 16 times per tile: 2.3 x the column pass.)
+// The forward sweep leaves the modified right-hand side in cur and the modified super-diagonal in tmp; the
+// backward sweep walks the row in reverse.  Row starts are only 4-byte aligned (ROI widths are arbitrary): the
+// 16-byte global accesses of gfx950 need no more.
+constexpr int FGS_T = 64, FGS_PD = 4;
 __device__ __forceinline__ void fgs_step(float w, float& c, float& t, float lambda, float& coef_prev, float& prev_cur,
                                          float& prev_tmp) {
     const float coef_cur = lambda * w;
@@ -1263,89 +1265,98 @@ __device__ __forceinline__ void fgs_step(float w, float& c, float& t, float lamb
     c = prev_cur;
     coef_prev = coef_cur;
 }
-// 64x64 tile <-> global, one row per wave-load (256 contiguous bytes), 8 rows in flight.  Rows past
-// nrows re-read the last valid row (never written back); columns past nc are skipped.
-__device__ __forceinline__ void fgs_tile_load(float (*t)[FGS_T + 1], const float* __restrict__ g, int rw, int nrows, int col,
-                                              bool colok, int lane) {
-    if (!colok) return;
-#pragma unroll 1
-    for (int r = 0; r < FGS_T; r += 8) {
-        float a[8];
+__device__ __forceinline__ void fgs_ld4(const float* __restrict__ p, float (&v)[4]) {
+    uint32_t r[4];
+    load_regs<4>(reinterpret_cast<const uint32_t*>(p), r);
 #pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = g[(size_t)min(r + u, nrows - 1) * rw + col];
-#pragma unroll
-        for (int u = 0; u < 8; u++) t[r + u][lane] = a[u];
-    }
+    for (int u = 0; u < 4; u++) v[u] = __uint_as_float(r[u]);
 }
-__device__ __forceinline__ void fgs_tile_store(const float (*t)[FGS_T + 1], float* __restrict__ g, int rw, int nrows, int col,
-                                               bool colok, int lane) {
-    if (!colok) return;
-    for (int r = 0; r < nrows; r++) g[(size_t)r * rw + col] = t[r][lane];
+__device__ __forceinline__ void fgs_st4(float* __restrict__ p, const float (&v)[4]) {
+    uint32_t r[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) r[u] = __float_as_uint(v[u]);
+    store_regs<4>(reinterpret_cast<uint32_t*>(p), r);
 }
 __global__ __launch_bounds__(64) void k_fgs_hpass(float* __restrict__ cur, const float* __restrict__ wh, float* __restrict__ tmp,
                                                    int rw, int rh, int K, float lambda) {
-    __shared__ float t_c[FGS_T][FGS_T + 1], t_w[FGS_T][FGS_T + 1], t_t[FGS_T][FGS_T + 1];
-    const int img = blockIdx.y, f = img / K, lane = threadIdx.x;
-    const int r0 = blockIdx.x * FGS_T, nrows = min(FGS_T, rh - r0);
-    float* curI = cur + ((size_t)img * rh + r0) * rw;
-    float* tmpI = tmp + ((size_t)img * rh + r0) * rw;
-    const float* whI = wh + ((size_t)f * rh + r0) * rw;
+    const int img = blockIdx.y, f = img / K;
+    const int row = blockIdx.x * FGS_T + threadIdx.x;
+    const bool rowok = row < rh;
+    const int rr = min(row, rh - 1);   // rows past the end repeat the last row (never written back)
+    float* curR = cur + ((size_t)img * rh + rr) * rw;
+    float* tmpR = tmp + ((size_t)img * rh + rr) * rw;
+    const float* whR = wh + ((size_t)f * rh + rr) * rw;
+    const int ng = rw / 4;   // full groups of four samples; the last rw % 4 samples go one by one
     float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
-    const int nchunks = (rw + FGS_T - 1) / FGS_T;
-    for (int c = 0; c < nchunks; c++) {
-        const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
-        fgs_tile_load(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
-        fgs_tile_load(t_w, whI, rw, nrows, c0 + lane, lane < nc, lane);
-        __syncthreads();
-        // rows past nrows solve garbage that is never written back
-        for (int j0 = 0; j0 < nc; j0 += FGS_R) {
-            float cc[FGS_R], ww[FGS_R], tt[FGS_R];
+    {
+        float c[FGS_PD][4], w[FGS_PD][4];
 #pragma unroll
-            for (int u = 0; u < FGS_R; u++) { cc[u] = t_c[lane][j0 + u]; ww[u] = t_w[lane][j0 + u]; }
-#pragma unroll
-            for (int u = 0; u < FGS_R; u++) {
-                tt[u] = 0.0f;
-                if (j0 + u < nc) fgs_step(ww[u], cc[u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
-            }
-#pragma unroll
-            for (int u = 0; u < FGS_R; u++) { t_c[lane][j0 + u] = cc[u]; t_t[lane][j0 + u] = tt[u]; }
+        for (int p = 0; p < FGS_PD; p++) {
+            const int g = min(p, max(ng - 1, 0));
+            if (ng > 0) { fgs_ld4(curR + 4 * g, c[p]); fgs_ld4(whR + 4 * g, w[p]); }
         }
-        __syncthreads();
-        fgs_tile_store(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
-        fgs_tile_store(t_t, tmpI, rw, nrows, c0 + lane, lane < nc, lane);
-        __syncthreads();
+        for (int g = 0; g < ng; g++) {
+            float cc[4], ww[4], tt[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { cc[u] = c[0][u]; ww[u] = w[0][u]; }
+#pragma unroll
+            for (int p = 0; p + 1 < FGS_PD; p++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) { c[p][u] = c[p + 1][u]; w[p][u] = w[p + 1][u]; }
+            const int gn = min(g + FGS_PD, ng - 1);   // past the end: an unused, in-bounds prefetch
+            fgs_ld4(curR + 4 * gn, c[FGS_PD - 1]);
+            fgs_ld4(whR + 4 * gn, w[FGS_PD - 1]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) fgs_step(ww[u], cc[u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
+            if (rowok) { fgs_st4(curR + 4 * g, cc); fgs_st4(tmpR + 4 * g, tt); }
+        }
+        for (int j = 4 * ng; j < rw; j++) {
+            float cc = curR[j], tt;
+            fgs_step(whR[j], cc, tt, lambda, coef_prev, prev_cur, prev_tmp);
+            if (rowok) { curR[j] = cc; tmpR[j] = tt; }
+        }
     }
-    float next = 0.0f;
-    for (int c = nchunks - 1; c >= 0; c--) {
-        const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
-        fgs_tile_load(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
-        fgs_tile_load(t_t, tmpI, rw, nrows, c0 + lane, lane < nc, lane);
-        __syncthreads();
-        for (int j0 = FGS_T - FGS_R; j0 >= 0; j0 -= FGS_R) {
-            float cc[FGS_R], tt[FGS_R];
+    // this lane reads back what it has just written
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // backward: the last sample of the row is final after the forward sweep
+    float next = prev_cur;
+    for (int j = rw - 2; j >= 4 * ng; j--) {
+        next = curR[j] - tmpR[j] * next;
+        if (rowok) curR[j] = next;
+    }
+    if (ng > 0) {
+        float c[FGS_PD][4], t[FGS_PD][4];
 #pragma unroll
-            for (int u = 0; u < FGS_R; u++) { cc[u] = t_c[lane][j0 + u]; tt[u] = t_t[lane][j0 + u]; }
-#pragma unroll
-            for (int u = FGS_R - 1; u >= 0; u--) {
-                const int j = j0 + u;
-                if (j < nc) {
-                    // the last sample of the row is final after the forward sweep
-                    next = (c0 + j == rw - 1) ? cc[u] : cc[u] - tt[u] * next;
-                    cc[u] = next;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < FGS_R; u++) t_c[lane][j0 + u] = cc[u];
+        for (int p = 0; p < FGS_PD; p++) {
+            const int g = max(ng - 1 - p, 0);
+            fgs_ld4(curR + 4 * g, c[p]);
+            fgs_ld4(tmpR + 4 * g, t[p]);
         }
-        __syncthreads();
-        fgs_tile_store(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
-        __syncthreads();
+        for (int g = ng - 1; g >= 0; g--) {
+            float cc[4], tt[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { cc[u] = c[0][u]; tt[u] = t[0][u]; }
+#pragma unroll
+            for (int p = 0; p + 1 < FGS_PD; p++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) { c[p][u] = c[p + 1][u]; t[p][u] = t[p + 1][u]; }
+            const int gn = max(g - FGS_PD, 0);
+            fgs_ld4(curR + 4 * gn, c[FGS_PD - 1]);
+            fgs_ld4(tmpR + 4 * gn, t[FGS_PD - 1]);
+#pragma unroll
+            for (int u = 3; u >= 0; u--) {
+                next = (4 * g + u == rw - 1) ? cc[u] : cc[u] - tt[u] * next;
+                cc[u] = next;
+            }
+            if (rowok) fgs_st4(curR + 4 * g, cc);
+        }
     }
 }
 
-// Column solves: one lane per column, rows walked in order (coalesced across the wave), FGS_V rows
-// per trip with the next trip's loads issued before the current chain is computed.
-constexpr int FGS_V = 8;
+// Column solves: one lane per column, rows walked in order (coalesced across the wave), FGS_V rows per trip with
+// the loads of FGS_VD trips in flight ahead of the solve chain.
+constexpr int FGS_V = 8, FGS_VD = 3;
 __global__ __launch_bounds__(64) void k_fgs_vpass(float* __restrict__ cur, const float* __restrict__ wv, float* __restrict__ tmp,
                                                    int rw, int rh, int K, float lambda) {
     const int j = min((int)(blockIdx.x * blockDim.x + threadIdx.x), rw - 1);  // surplus lanes repeat the last column
@@ -1354,22 +1365,28 @@ __global__ __launch_bounds__(64) void k_fgs_vpass(float* __restrict__ cur, const
     float* tmpI = tmp + (size_t)img * rh * rw + j;
     const float* wvI = wv + (size_t)f * rh * rw + j;
     float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
-    float cn[FGS_V], wn[FGS_V];
+    float cn[FGS_VD][FGS_V], wn[FGS_VD][FGS_V];
 #pragma unroll
-    for (int u = 0; u < FGS_V; u++) {
-        const size_t o = (size_t)min(u, rh - 1) * rw;
-        cn[u] = curI[o];
-        wn[u] = wvI[o];
-    }
+    for (int p = 0; p < FGS_VD; p++)
+#pragma unroll
+        for (int u = 0; u < FGS_V; u++) {
+            const size_t o = (size_t)min(p * FGS_V + u, rh - 1) * rw;
+            cn[p][u] = curI[o];
+            wn[p][u] = wvI[o];
+        }
     for (int i0 = 0; i0 < rh; i0 += FGS_V) {
         float cc[FGS_V], ww[FGS_V], tt[FGS_V];
 #pragma unroll
-        for (int u = 0; u < FGS_V; u++) { cc[u] = cn[u]; ww[u] = wn[u]; }
+        for (int u = 0; u < FGS_V; u++) { cc[u] = cn[0][u]; ww[u] = wn[0][u]; }
+#pragma unroll
+        for (int p = 0; p + 1 < FGS_VD; p++)
+#pragma unroll
+            for (int u = 0; u < FGS_V; u++) { cn[p][u] = cn[p + 1][u]; wn[p][u] = wn[p + 1][u]; }
 #pragma unroll
         for (int u = 0; u < FGS_V; u++) {
-            const size_t o = (size_t)min(i0 + FGS_V + u, rh - 1) * rw;
-            cn[u] = curI[o];
-            wn[u] = wvI[o];
+            const size_t o = (size_t)min(i0 + FGS_VD * FGS_V + u, rh - 1) * rw;
+            cn[FGS_VD - 1][u] = curI[o];
+            wn[FGS_VD - 1][u] = wvI[o];
         }
 #pragma unroll
         for (int u = 0; u < FGS_V; u++)
@@ -1379,26 +1396,34 @@ __global__ __launch_bounds__(64) void k_fgs_vpass(float* __restrict__ cur, const
                 curI[(size_t)(i0 + u) * rw] = cc[u];
             }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // backward: rows rh-2 .. 0 (row rh-1 is final); trips aligned to the same FGS_V grid
     float next = prev_cur;
     const int ilast = rh - 2;
     if (ilast < 0) return;
     int i0 = ilast - ilast % FGS_V;
 #pragma unroll
-    for (int u = 0; u < FGS_V; u++) {
-        const size_t o = (size_t)min(i0 + u, rh - 1) * rw;
-        cn[u] = curI[o];
-        wn[u] = tmpI[o];
-    }
+    for (int p = 0; p < FGS_VD; p++)
+#pragma unroll
+        for (int u = 0; u < FGS_V; u++) {
+            const size_t o = (size_t)min(max(i0 - p * FGS_V + u, 0), rh - 1) * rw;
+            cn[p][u] = curI[o];
+            wn[p][u] = tmpI[o];
+        }
     for (; i0 >= 0; i0 -= FGS_V) {
         float cc[FGS_V], tt[FGS_V];
 #pragma unroll
-        for (int u = 0; u < FGS_V; u++) { cc[u] = cn[u]; tt[u] = wn[u]; }
+        for (int u = 0; u < FGS_V; u++) { cc[u] = cn[0][u]; tt[u] = wn[0][u]; }
+#pragma unroll
+        for (int p = 0; p + 1 < FGS_VD; p++)
+#pragma unroll
+            for (int u = 0; u < FGS_V; u++) { cn[p][u] = cn[p + 1][u]; wn[p][u] = wn[p + 1][u]; }
 #pragma unroll
         for (int u = 0; u < FGS_V; u++) {
-            const size_t o = (size_t)max(i0 - FGS_V + u, 0) * rw;
-            cn[u] = curI[o];
-            wn[u] = tmpI[o];
+            const size_t o = (size_t)max(i0 - FGS_VD * FGS_V + u, 0) * rw;
+            cn[FGS_VD - 1][u] = curI[o];
+            wn[FGS_VD - 1][u] = tmpI[o];
         }
 #pragma unroll
         for (int u = FGS_V - 1; u >= 0; u--)
