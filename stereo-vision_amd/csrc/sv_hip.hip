@@ -679,8 +679,13 @@ int wls_dev(sv_ctx* c, int nf, const int16_t* d16, const uint8_t* vis, const uin
     hipLaunchKernelGGL(svk::k_wls_load, dim3((rw + 255) / 256, rh, nimg), b, 0, c->stream, d16, vis, cur, W, H, rx, ry, rw, rh, K);
     float lam = lambda;
     for (int it = 0; it < 3; it++) {  // fastGlobalSmootherFilter defaults: 3 iterations, attenuation 0.25
-        hipLaunchKernelGGL(svk::k_fgs_hpass, dim3((rh + svk::FGS_T - 1) / svk::FGS_T, nimg), dim3(64), 0, c->stream, cur, wh, tmp,
-                           rw, rh, K, lam);
+        // one wave per 64 rows: few waves (a single frame) -> the lane-per-row form, whose latency is the solve chain alone;
+        // many (a batch) -> the tile form, whose accesses are coalesced
+        const dim3 hgrid((rh + svk::FGS_T - 1) / svk::FGS_T, nimg);
+        if ((long)hgrid.x * hgrid.y <= 4L * c->n_cu)
+            hipLaunchKernelGGL(svk::k_fgs_hpass, hgrid, dim3(64), 0, c->stream, cur, wh, tmp, rw, rh, K, lam);
+        else
+            hipLaunchKernelGGL(svk::k_fgs_hpass_tiles, hgrid, dim3(64), 0, c->stream, cur, wh, tmp, rw, rh, K, lam);
         hipLaunchKernelGGL(svk::k_fgs_vpass, dim3((rw + 63) / 64, nimg), dim3(64), 0, c->stream, cur, wv, tmp, rw, rh, K, lam);
         lam *= 0.25f;
     }

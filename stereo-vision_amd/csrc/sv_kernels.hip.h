@@ -1354,6 +1354,94 @@ __global__ __launch_bounds__(64) void k_fgs_hpass(float* __restrict__ cur, const
     }
 }
 
+// The row pass for LARGE launches (many frames: hundreds of waves per CU over the launch): the lane-per-row form
+// above issues 64 different cache lines per access, which the texture-address path of a busy CU cannot keep
+// up with (1.8 ms per 128-frame pass against 0.86 ms); this form moves 64x64 tiles between HBM / L2 and LDS with
+// coalesced accesses and lets the solving lane read along its own LDS row (stride 65 words: conflict-free), the
+// other waves of the CU covering its load / solve / store phases.  Inside a tile the lane moves FGS_R samples at a
+// time between LDS and registers.  Two tiles of LDS per wave (the super-diagonal takes the weights' place).
+constexpr int FGS_R = 16;
+// 64x64 tile <-> global, one row per wave-load (256 contiguous bytes), 8 rows in flight.  Rows past
+// nrows re-read the last valid row (never written back); columns past nc are skipped.
+__device__ __forceinline__ void fgs_tile_load(float (*t)[FGS_T + 1], const float* __restrict__ g, int rw, int nrows, int col,
+                                              bool colok, int lane) {
+    if (!colok) return;
+#pragma unroll 1
+    for (int r = 0; r < FGS_T; r += 8) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = g[(size_t)min(r + u, nrows - 1) * rw + col];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[r + u][lane] = a[u];
+    }
+}
+__device__ __forceinline__ void fgs_tile_store(const float (*t)[FGS_T + 1], float* __restrict__ g, int rw, int nrows, int col,
+                                               bool colok, int lane) {
+    if (!colok) return;
+    for (int r = 0; r < nrows; r++) g[(size_t)r * rw + col] = t[r][lane];
+}
+__global__ __launch_bounds__(64) void k_fgs_hpass_tiles(float* __restrict__ cur, const float* __restrict__ wh, float* __restrict__ tmp,
+                                                   int rw, int rh, int K, float lambda) {
+    __shared__ float t_c[FGS_T][FGS_T + 1], t_w[FGS_T][FGS_T + 1];   // t_w: the weights on the way in, the super-diagonal on the way out / back in
+    float (*const t_t)[FGS_T + 1] = t_w;
+    const int img = blockIdx.y, f = img / K, lane = threadIdx.x;
+    const int r0 = blockIdx.x * FGS_T, nrows = min(FGS_T, rh - r0);
+    float* curI = cur + ((size_t)img * rh + r0) * rw;
+    float* tmpI = tmp + ((size_t)img * rh + r0) * rw;
+    const float* whI = wh + ((size_t)f * rh + r0) * rw;
+    float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
+    const int nchunks = (rw + FGS_T - 1) / FGS_T;
+    for (int c = 0; c < nchunks; c++) {
+        const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
+        fgs_tile_load(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
+        fgs_tile_load(t_w, whI, rw, nrows, c0 + lane, lane < nc, lane);
+        __syncthreads();
+        // rows past nrows solve garbage that is never written back
+        for (int j0 = 0; j0 < nc; j0 += FGS_R) {
+            float cc[FGS_R], ww[FGS_R], tt[FGS_R];
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) { cc[u] = t_c[lane][j0 + u]; ww[u] = t_w[lane][j0 + u]; }
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) {
+                tt[u] = 0.0f;
+                if (j0 + u < nc) fgs_step(ww[u], cc[u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
+            }
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) { t_c[lane][j0 + u] = cc[u]; t_t[lane][j0 + u] = tt[u]; }
+        }
+        __syncthreads();
+        fgs_tile_store(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
+        fgs_tile_store(t_t, tmpI, rw, nrows, c0 + lane, lane < nc, lane);
+        __syncthreads();
+    }
+    float next = 0.0f;
+    for (int c = nchunks - 1; c >= 0; c--) {
+        const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
+        fgs_tile_load(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
+        fgs_tile_load(t_t, tmpI, rw, nrows, c0 + lane, lane < nc, lane);
+        __syncthreads();
+        for (int j0 = FGS_T - FGS_R; j0 >= 0; j0 -= FGS_R) {
+            float cc[FGS_R], tt[FGS_R];
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) { cc[u] = t_c[lane][j0 + u]; tt[u] = t_t[lane][j0 + u]; }
+#pragma unroll
+            for (int u = FGS_R - 1; u >= 0; u--) {
+                const int j = j0 + u;
+                if (j < nc) {
+                    // the last sample of the row is final after the forward sweep
+                    next = (c0 + j == rw - 1) ? cc[u] : cc[u] - tt[u] * next;
+                    cc[u] = next;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FGS_R; u++) t_c[lane][j0 + u] = cc[u];
+        }
+        __syncthreads();
+        fgs_tile_store(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
+        __syncthreads();
+    }
+}
+
 // Column solves: one lane per column, rows walked in order (coalesced across the wave), FGS_V rows per trip with
 // the loads of FGS_VD trips in flight ahead of the solve chain.
 constexpr int FGS_V = 8, FGS_VD = 3;

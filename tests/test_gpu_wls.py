@@ -70,3 +70,33 @@ def test_wls_batched_and_rectified_guide(gpu):
     d = m.compute_rgb(lrgb, rrgb, rectify=False)
     assert np.array_equal(m.filter_wls(d), svref.wls_filter(d, lrgb, roi, 4500.0, 1.0))
     m.close()
+
+
+def test_wls_large_batch_uses_the_tile_row_pass(gpu):
+    """A launch with more than four waves per CU switches the row pass from the lane-per-row kernel to the LDS-tile
+    kernel (k_fgs_hpass_tiles): 300 frames of a ragged ROI (not a multiple of the 64x64 tiles), 16-bit map + vis,
+    every frame against the oracle's result for its pair."""
+    import torch
+    W, H, D, nb, nd = 173, 101, 32, 300, 6
+    ph, po = _params(D, 8)
+    rng = np.random.default_rng(9)
+    pairs = [synth.stereo_pair(60 + i, W, H, D) for i in range(nd)]
+    guides = [synth.rgb_from_gray(rng, p[0]) for p in pairs]
+    m = svhip.Matcher(W, H, ph)
+    disps = [m.compute_gray(p[0], p[1]) for p in pairs]
+    viss = [m.disparity_vis(d, 3) for d in disps]
+    dt = torch.from_numpy(np.stack([disps[i % nd] for i in range(nb)])).cuda()
+    vt = torch.from_numpy(np.stack([viss[i % nd] for i in range(nb)])).cuda()
+    gt = torch.from_numpy(np.stack([guides[i % nd] for i in range(nb)])).cuda()
+    o16, o8 = torch.empty_like(dt), torch.empty_like(vt)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.filter_wls_dev(nb, dt, gt, o16, vt, o8)
+    torch.cuda.synchronize()
+    roi = m.wls_roi()
+    assert ((roi[3] + 63) // 64) * nb * 2 > 4 * 256   # really the tile kernel
+    got16, got8 = o16.cpu().numpy(), o8.cpu().numpy()
+    for i in range(nd):
+        e16, e8 = svref.wls_filter(disps[i], guides[i], roi, 4500.0, 1.0, vis=viss[i])
+        for k in range(i, nb, nd):
+            assert np.array_equal(got16[k], e16) and np.array_equal(got8[k], e8), k
+    m.close()
