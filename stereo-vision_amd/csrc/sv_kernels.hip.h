@@ -526,22 +526,47 @@ __device__ __forceinline__ uint32_t wta_threshold(uint32_t minS, UniqK uq) {
     return __umulhi(minS * uq.k + uq.add, uq.magic);
 }
 
-template <int N>
-__device__ __forceinline__ WtaPart wta_reduce(const uint32_t (&s)[N], int q, UniqK uq) {
-    const int dbase = q * 2 * N;
-    // first minimum: packed key (S << 16 | d) under a 32-bit min
+// all-lanes row reductions written with the DPP builtins only (no inline asm): inside one basic block the compiler
+// folds every stage into one v_*_dpp and is free to fill the two wait states a DPP read needs with other work
+__device__ __forceinline__ uint32_t row16_min_u32_s(uint32_t v) {
+    v = min(v, dpp<DPP_QUAD_XOR1>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_QUAD_XOR2>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_ROW_HALF_MIRROR>(0xFFFFFFFFu, v));
+    return min(v, dpp<DPP_ROW_MIRROR>(0xFFFFFFFFu, v));
+}
+__device__ __forceinline__ uint32_t row16_add_u32_s(uint32_t v) {
+    v += dpp<DPP_QUAD_XOR1>(0u, v);
+    v += dpp<DPP_QUAD_XOR2>(0u, v);
+    v += dpp<DPP_ROW_HALF_MIRROR>(0u, v);
+    return v + dpp<DPP_ROW_MIRROR>(0u, v);
+}
+__device__ __forceinline__ uint32_t row16_or_u32_s(uint32_t v) {
+    v |= dpp<DPP_QUAD_XOR1>(0u, v);
+    v |= dpp<DPP_QUAD_XOR2>(0u, v);
+    v |= dpp<DPP_ROW_HALF_MIRROR>(0u, v);
+    return v | dpp<DPP_ROW_MIRROR>(0u, v);
+}
+
+// The three reductions of wta_reduce as separate stages (k_sweep spreads them over a step, next to the path
+// arithmetic of the following pixel, so that their dependent DPP chains do not sit idle on wait states).
+// A: first minimum: packed key (S << 16 | d) under a 32-bit min.  Inside the lane the key carries the position within
+// the lane (an inline constant: no register per position); the lane's base is added to the lane's minimum.
+template <int N, bool SCHED>
+__device__ __forceinline__ uint32_t wta_stage_key(const uint32_t (&s)[N], int q) {
     uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        key = min(key, (s[k] << 16) | (uint32_t)(dbase + 2 * k));
-        key = min(key, (s[k] & 0xFFFF0000u) | (uint32_t)(dbase + 2 * k + 1));
+        key = min(key, (s[k] << 16) | (uint32_t)(2 * k));
+        key = min(key, (s[k] & 0xFFFF0000u) | (uint32_t)(2 * k + 1));
     }
-    key = row16_min_u32(key);
-    const int best = (int)(key & 0xFFFFu);
-    // uniqueness: no S outside best-1..best+1 may be below T.  Every S lies in [0, 32767], so with T
-    // clamped to 32768 "S < T" is the sign of the 16-bit difference: count the hits over all
-    // disparities; wta_finish compares the count with the hits
-    // among the three exempt positions.
+    key += (uint32_t)(q * 2 * N);   // 2N - 1 + dbase < 256: no carry into S
+    return SCHED ? row16_min_u32_s(key) : row16_min_u32(key);
+}
+// B: uniqueness: no S outside best-1..best+1 may be below T.  Every S lies in [0, 32767], so with T
+// clamped to 32768 "S < T" is the sign of the 16-bit difference: count the hits over all disparities;
+// wta_finish compares the count with the hits among the three exempt positions.
+template <int N, bool SCHED>
+__device__ __forceinline__ uint32_t wta_stage_count(const uint32_t (&s)[N], uint32_t key, UniqK uq) {
     const uint32_t T = wta_threshold(key >> 16, uq);
     const uint32_t Tc = min(T, 0x8000u), TT = Tc | (Tc << 16);
     // sign bits of two registers' differences gathered into one word (v_perm), counted by v_bcnt
@@ -552,11 +577,15 @@ __device__ __forceinline__ WtaPart wta_reduce(const uint32_t (&s)[N], int q, Uni
         cnt += (uint32_t)__builtin_popcount(g & 0x80808080u);
     }
     if (N & 1) cnt += (uint32_t)__builtin_popcount(pk_sub(s[N - 1], TT) & 0x80008000u);
-    cnt = row16_add_u32(cnt);
-    // S[best-1] and S[best+1]: positions p and p+2 of the owning lane, 0 elsewhere, OR-reduced.
-    // Both have the parity of p and sit in registers kq = p >> 1 and kq + 1 (either may lie outside
-    // this lane: then the neighbouring lane supplies the value).
-    const int p = best - 1 - dbase;  // position of best-1 in this lane's 2N values (may lie outside)
+    return SCHED ? row16_add_u32_s(cnt) : row16_add_u32(cnt);
+}
+// C: S[best-1] and S[best+1]: positions p and p+2 of the owning lane, 0 elsewhere, OR-reduced.
+// Both have the parity of p and sit in registers kq = p >> 1 and kq + 1 (either may lie outside
+// this lane: then the neighbouring lane supplies the value).
+template <int N, bool SCHED>
+__device__ __forceinline__ uint32_t wta_stage_neighbours(const uint32_t (&s)[N], uint32_t key, int q) {
+    const int best = (int)(key & 0xFFFFu);
+    const int p = best - 1 - q * 2 * N;  // position of best-1 in this lane's 2N values (may lie outside)
     const int kq = p >> 1;
     uint32_t vm = 0u, vp = 0u;
 #pragma unroll
@@ -565,8 +594,15 @@ __device__ __forceinline__ WtaPart wta_reduce(const uint32_t (&s)[N], int q, Uni
         vp = kq == k - 1 ? s[k] : vp;
     }
     // the low (p even) or high (p odd) halves of both: S[best-1] into the high half, S[best+1] into the low half
-    uint32_t nb = __builtin_amdgcn_perm(vm, vp, (p & 1) ? 0x07060302u : 0x05040100u);
-    nb = row16_or_u32(nb);
+    const uint32_t nb = __builtin_amdgcn_perm(vm, vp, (p & 1) ? 0x07060302u : 0x05040100u);
+    return SCHED ? row16_or_u32_s(nb) : row16_or_u32(nb);
+}
+
+template <int N>
+__device__ __forceinline__ WtaPart wta_reduce(const uint32_t (&s)[N], int q, UniqK uq) {
+    const uint32_t key = wta_stage_key<N, false>(s, q);
+    const uint32_t cnt = wta_stage_count<N, false>(s, key, uq);
+    const uint32_t nb = wta_stage_neighbours<N, false>(s, key, q);
     // best < 256 and the count only matters up to 4 (at most three positions are exempt): both fit the low half
     return WtaPart{key | (min(cnt, 255u) << 8), nb};
 }

@@ -36,7 +36,13 @@ namespace svk {
 
 constexpr int SW_RING = 16;   // pixels in the import / export rings
 constexpr int SW_LEAD = 32;   // loop steps before stream pixel 0 (service pipeline warm-up), multiple of 4
-constexpr int SW_DEPTH = 4;   // global-load pipeline depth in steps
+#ifndef SV_SW_DEPTH
+#define SV_SW_DEPTH 2
+#endif
+static_assert(SV_SW_DEPTH == 2 || SV_SW_DEPTH == 4, "even, and the import runs at most six pixels ahead of the counter check");
+constexpr int SW_DEPTH = SV_SW_DEPTH;   // global-load pipeline depth in steps (even: the record slots alternate with the step's parity).
+                                        // A step takes ~2 us, longer than an HBM access: two steps of loads in flight are enough,
+                                        // and each step of depth costs 2N registers of a 128-register budget
 // Bound of every wait on a neighbouring band, in ticks of the constant 100 MHz counter (s_memrealtime): 2 s of
 // time actually spent polling.  One poll interval counts for at most SW_WAIT_TICK_CAP ticks, so a pause of the
 // whole queue (another process's kernels time-sliced onto the GPU) does not run the bound out.
@@ -95,7 +101,13 @@ __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_
         L[k] = c[k] - pk_sub_sat(dd, t);
         mn = pk_min(mn, L[k]);
     }
-    mn_out = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));  // this lane's minimum in both halves; the row's: row16_min_1p3
+    mn_out = mn;  // the minima of the even and of the odd disparities of this lane; sweep_lane_min joins the halves
+}
+// the four paths' lane minima, in both halves of the word; together, so that the four two-instruction chains interleave
+__device__ __forceinline__ void sweep_lane_min4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    const uint32_t ta = __builtin_amdgcn_alignbit(a, a, 16), tb = __builtin_amdgcn_alignbit(b, b, 16);
+    const uint32_t tc = __builtin_amdgcn_alignbit(c, c, 16), td = __builtin_amdgcn_alignbit(d, d, 16);
+    a = pk_min(a, ta); b = pk_min(b, tb); c = pk_min(c, tc); d = pk_min(d, td);
 }
 
 #ifdef SV_SWEEP_PROF
@@ -172,6 +184,9 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     const UniqK uqk = make_uniq(a.uniq);
     WtaPart stash = {0u, 0u};              // sweep 2: reduced WTA words of the pixel this lane will finish
     uint32_t stash_rq = 0xFFFFFFFFu;       // ... and its record index (all ones: nothing kept)
+    uint32_t sp[N], sp_rq = 0xFFFFFFFFu;   // sweep 2: finished S of the previous step's pixel and its record index (its WTA runs this step)
+#pragma unroll
+    for (int k = 0; k < N; k++) sp[k] = 0;
     const uint32_t big0 = q == 0 ? 0x7FFF7FFFu : 0u, big15 = q == 15 ? 0x7FFF7FFFu : 0u;  // see sweep_path
     uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH], recq[SW_DEPTH];
     uint32_t lrbase = 0;                             // index of frame lfi's first WTA record
@@ -235,30 +250,45 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 // row and frame, so the reset sits behind a wave-uniform branch instead of in every step.
                 const bool st_l = x == 0, st_r = x == W1 - 1;
                 if (__builtin_amdgcn_ballot_w64(st_l || st_r) != 0) {
+                    // In place (tied asm operands): written as plain selects the compiler gives the results new registers
+                    // and pays for it with ~19 v_mov on the common path, where this block is skipped.
                     const uint32_t kl = st_l ? 0u : 0xFFFFFFFFu, kr = st_r ? 0u : 0xFFFFFFFFu;
+                    const uint32_t pl = st_l ? P2P2 : 0u, pr = st_r ? P2P2 : 0u;   // dd = (dd & k) | p
 #pragma unroll
-                    for (int k = 0; k < N; k++) { r0[k] &= kl; dr[j & 1][k] &= kl; in_dl[k] &= kr; }
-                    dd0 = st_l ? P2P2 : dd0;
-                    dr_dd[j & 1] = st_l ? P2P2 : dr_dd[j & 1];
-                    dd_dl = st_r ? P2P2 : dd_dl;
+                    for (int k = 0; k < N; k++) {
+                        asm volatile("v_and_b32 %0, %0, %1" : "+v"(r0[k]) : "v"(kl));
+                        asm volatile("v_and_b32 %0, %0, %1" : "+v"(dr[j & 1][k]) : "v"(kl));
+                        asm volatile("v_and_b32 %0, %0, %1" : "+v"(in_dl[k]) : "v"(kr));
+                    }
+                    asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(dd0) : "v"(kl), "v"(pl));
+                    asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(dr_dd[j & 1]) : "v"(kl), "v"(pl));
+                    asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(dd_dl) : "v"(kr), "v"(pr));
                 }
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
                 // Own record for the row below.  Its three L parts leave as soon as each is computed: a 16-byte
                 // LDS store occupies the store path for ~13 cycles per wave, 15 waves x 3 of them bunched in
                 // front of the barrier would leave the VALUs idle for that long; issued early they overlap with
                 // the other waves' arithmetic.  (The row below reads this buffer only after the barrier.)
+                // Sweep 2: winner-take-all of the PREVIOUS step's pixel (its finished S waits in sp) runs in three
+                // stages next to the first three paths: each stage is a dependent chain that ends in a four-step DPP
+                // butterfly, and alone it would spend a third of its issue slots on wait states.
                 uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
                                                    : slot + ((j & 1) * (SW_ROWS + 1) + r + 1) * REC;
+                uint32_t w_key = 0, w_cnt = 0, w_nb = 0;
                 sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, L1, n1, big0, big15);   // from (x-1, y-1): read two steps ago
                 store_regs<N>(dst + 2 * PXW + q * N, L1);
+                if (SECOND) w_key = wta_stage_key<N, true>(sp, q);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], dn, dn_dd, P1P1, L2, n2, big0, big15);               // from (x,   y-1): read last step
                 store_regs<N>(dst + PXW + q * N, L2);
+                if (SECOND) w_cnt = wta_stage_count<N, true>(sp, w_key, uqk);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, L3, n3, big0, big15);            // from (x+1, y-1): read now
                 store_regs<N>(dst + q * N, L3);
+                if (SECOND) w_nb = wta_stage_neighbours<N, true>(sp, w_key, q);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal: stays in registers
+                sweep_lane_min4(n0, n1, n2, n3);
                 // min over d of every path: the horizontal one into every lane (this row's next step), the
                 // other three only into the record (tail words 0-3: path 3, 4-7: path 2, 8-11: path 1)
                 uint32_t nq;
@@ -270,6 +300,20 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 dr_dd[j & 1] = src[3 * PXW + 8];
                 SW_STAMP(T2)
                 dst[3 * PXW + q] = nq + P2P2;
+                if (SECOND) {
+                    // The reductions leave the same three words in all 16 lanes of the row's group;
+                    // lane (pixel's step mod 16) keeps them, and once per 16 steps every lane finishes the
+                    // pixel it kept (thresholds, sub-pixel division, record) and stores its record:
+                    // the lane-local arithmetic runs once per 16 pixels instead of 16-fold redundantly.
+                    const bool mine = q == ((tau + j - 1) & 15);   // sp is the pixel of step tau + j - 1
+                    stash.key = mine ? (w_key | (min(w_cnt, 255u) << 8)) : stash.key;
+                    stash.nb = mine ? w_nb : stash.nb;
+                    stash_rq = mine ? sp_rq : stash_rq;
+                    if (j == 0 && (tau & 15) == 0) {               // the pixel just kept was the 16th
+                        if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk, a.min_disp);
+                        stash_rq = 0xFFFFFFFFu;
+                    }
+                }
                 uint32_t snew[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) {
@@ -282,19 +326,9 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 }
                 dd0 = n0 + P2P2;
                 if (SECOND) {
-                    // The reductions leave the same three words in all 16 lanes of the row's group;
-                    // lane (step mod 16) keeps them, and once per 16 steps every lane finishes the
-                    // pixel it kept (thresholds, sub-pixel division, record) and stores its record:
-                    // the lane-local arithmetic runs once per 16 pixels instead of 16-fold redundantly.
-                    const WtaPart w = wta_reduce<N>(snew, q, uqk);
-                    const bool mine = q == ((tau + j) & 15);
-                    stash.key = mine ? w.key : stash.key;
-                    stash.nb = mine ? w.nb : stash.nb;
-                    stash_rq = mine ? (active ? recq[j] : 0xFFFFFFFFu) : stash_rq;
-                    if (j == SW_DEPTH - 1 && ((tau + j) & 15) == 15) {
-                        if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk, a.min_disp);
-                        stash_rq = 0xFFFFFFFFu;
-                    }
+#pragma unroll
+                    for (int k = 0; k < N; k++) sp[k] = snew[k];
+                    sp_rq = active ? recq[j] : 0xFFFFFFFFu;
                 } else {
                     if (active) store_regs<N>(Sg + offq[j], snew);
                 }
@@ -307,8 +341,18 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 SW_PROF(pacc[0] += T1 - T0; pacc[1] += T2 - T1; pacc[2] += T3 - T2; pacc[3] += T4 - T3;)
             }
         }
-        // pixels kept since the last 16-step boundary
-        if (SECOND && stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk, a.min_disp);
+        if (SECOND) {
+            // the pixel of the last step the loop ran (it runs whole groups of SW_DEPTH steps), then the pixels kept since
+            // the last 16-step boundary
+            const int last_step = -SW_LEAD + SW_DEPTH * ((tau_end + SW_LEAD + SW_DEPTH - 1) / SW_DEPTH) - 1;
+            const uint32_t w_key = wta_stage_key<N, false>(sp, q), w_cnt = wta_stage_count<N, false>(sp, w_key, uqk);
+            const uint32_t w_nb = wta_stage_neighbours<N, false>(sp, w_key, q);
+            const bool mine = q == (last_step & 15);
+            stash.key = mine ? (w_key | (min(w_cnt, 255u) << 8)) : stash.key;
+            stash.nb = mine ? w_nb : stash.nb;
+            stash_rq = mine ? sp_rq : stash_rq;
+            if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk, a.min_disp);
+        }
         SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
     } else {
         bool aborted = false;
@@ -319,7 +363,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
             for (int j = 0; j < SW_DEPTH; j++) {
                 const int t = tau + j;
                 SW_STAMP(T0)
-                // import: pixel t + 2 of the previous band's last row (loaded four steps ago) -> ring;
+                // import: pixel t + 2 of the previous band's last row (loaded SW_DEPTH steps ago) -> ring;
                 // row 0 reads pixel t' - 1 at step t'.
                 if (do_import) {
                     if ((t & 15) == 0 && t + 23 > 0) {
@@ -341,7 +385,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
                     for (int i = 0; i < NQ; i++)
                         if (lane + 64 * i < RECQ) reinterpret_cast<unsigned long long*>(w)[lane + 64 * i] = ib[j][i];
-                    const int p = t + 6;
+                    const int p = t + 2 + SW_DEPTH;   // <= t + 6: covered by the counter value waited for (t + 23 at t % 16 == 0)
                     const unsigned long long* g = ho_in + (size_t)((p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
 #pragma unroll
                     for (int i = 0; i < NQ; i++)
