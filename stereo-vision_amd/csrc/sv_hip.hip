@@ -94,7 +94,7 @@ struct sv_ctx {
     bool bslots_ok = false;
     long next_batch_ticket = 0;
     // fused four-path sweeps (sv_sweep.hip.h)
-    Buf sw_handoff, sw_progress, sw_sink, sw_prof;
+    Buf sw_handoff, sw_progress, sw_sink, sw_prof, cost_sink;
     int sw_prof_n = 0;
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
@@ -420,10 +420,11 @@ int launch_cost2_n(sv_ctx* c, int nb) {
     const bool by_xcd = nb >= 8;  // below that the frame -> XCD order would leave XCDs idle
     const size_t n_wg = (size_t)ntx * nbands * (by_xcd ? (nb + 7) / 8 * 8 : nb);
     if (n_wg > 0x7FFFFFFFu) return fail(c, SV_ERR_UNSUPPORTED, "batch too large for one cost launch");
+    if (int rc = ensure(c, c->cost_sink, (size_t)svk::COST_SINK_SLOTS * NT * N * 4)) return rc;
     hipLaunchKernelGGL((svk::k_cost2<N, NT, CN>), dim3((unsigned)n_wg), dim3(NT), lds, c->stream,
                        (const uint2*)c->stat_l.p, (const uint16_t*)c->stat_r.p, (uint32_t*)c->C.p, W, H, WP, r, yband,
                        (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0, ntx, nbands, by_xcd ? nb : -nb,
-                       geo_col0(W, p), W1, p.min_disparity);
+                       geo_col0(W, p), W1, p.min_disparity, (uint32_t*)c->cost_sink.p);
     if (H > 1)
         hipLaunchKernelGGL(svk::k_cost_col0, dim3(H - 1, nb), dim3(128), 0, c->stream, (uint32_t*)c->C.p, W1, H, D / 2,
                            (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0);
@@ -491,7 +492,7 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     int rc;
     if ((rc = ensure(c, c->sw_handoff, (size_t)n_groups * (n_bands > 1 ? n_bands - 1 : 1) * (size_t)(ho_px + 1) * REC * 4))) return rc;
     if ((rc = ensure(c, c->sw_progress, (size_t)n_groups * n_bands * 4))) return rc;
-    if ((rc = ensure(c, c->sw_sink, (size_t)grid * NTHR * 16))) return rc;
+    if ((rc = ensure(c, c->sw_sink, (size_t)grid * NTHR * N * 4))) return rc;
     bool& attr_set = c->attr_sweep[second][N - 1][CW == 15];  // [2][8][2]  // per context: the attribute is per device
     if (!attr_set) {
         const void* fn = second ? reinterpret_cast<const void*>(&svk::k_sweep<N, true, CW>) : reinterpret_cast<const void*>(&svk::k_sweep<N, false, CW>);
@@ -927,7 +928,7 @@ int sv_destroy(sv_ctx* c) {
                           &c->disp_lr, &c->out, &c->rgb_l, &c->rgb_r, &c->rect_l, &c->rect_r, &c->gray_l, &c->gray_r,
                           &c->maps[0], &c->maps[1], &c->maps[2], &c->maps[3], &c->mapper, &c->mapper_lr[0], &c->mapper_lr[1], &c->depth, &c->d16tmp, &c->vis,
                           &c->lab, &c->cnt, &c->wls_lut, &c->wls_wh, &c->wls_wv, &c->wls_cur, &c->wls_tmp, &c->wls_g,
-                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->world_cart, &c->world_cyl, &c->blf_a, &c->blf_b, &c->blf_mm, &c->blf_o16, &c->blf_o8, &c->blf_tab, &c->blf_tmp, &c->blf_gray, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof};
+                          &c->wls_v, &c->wls_o16, &c->wls_o8, &c->world_cart, &c->world_cyl, &c->blf_a, &c->blf_b, &c->blf_mm, &c->blf_o16, &c->blf_o8, &c->blf_tab, &c->blf_tmp, &c->blf_gray, &c->sw_handoff, &c->sw_progress, &c->sw_sink, &c->sw_prof, &c->cost_sink};
             for (Buf* b : all) release(*b);
             if (c->sw_error) (void)hipHostFree(c->sw_error);
             if (c->slots_ok)

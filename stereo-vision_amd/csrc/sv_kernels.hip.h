@@ -332,11 +332,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // BT phase: the costs of tile column j for its 2N disparities -> LDS; window phase (j < TX): the
 // 2r+1-tap horizontal sum for output column j from LDS, the last 2r+2 sums in a private LDS ring,
 // the vertical running sum in registers, C out with the 16-byte stores k_agg / k_sweep read back.
+constexpr int COST_SINK_SLOTS = 256;   // sink slots of NT * N dwords each (workgroup id mod 256)
 template <int N, int NT, int CN>
 __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
                                                uint32_t* __restrict__ C, int W, int H, int WP, int radius, int yband,
                                                uint32_t P2P2, int tail_p2, int ntx, int nbands, int nframes, int col0, int W1,
-                                               int min_disp) {
+                                               int min_disp, uint32_t* __restrict__ sink) {
     constexpr int cn = CN;  // colour planes summed into the cost (1 = gray, 3 = RGB)
     extern __shared__ __align__(16) uint32_t c2_lds[];
     constexpr int D2 = 16 * N, NCOL = NT / 16;
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     const int ylast = H - 1 - radius;
     const int ys = min(y0, ylast);
     uint32_t* Cout = C + (size_t)min(xl, W1 - 1) * D2 + q * N;
+    uint32_t* const sinkp = sink + ((size_t)(blockIdx.x & (COST_SINK_SLOTS - 1)) * NT + tid) * N;   // shared by workgroups: never read
     const size_t rowN = (size_t)W1 * D2;
     // The rows of the band as a software pipeline, one LDS-only barrier per image row: after the
     // barrier the window taps of row ry are requested from pix[ry & 1] (all of them in flight: the
@@ -420,22 +422,30 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
         constexpr int TAPS = decltype(taps_tag)::value;
         const int r_begin = max(ys - radius, 0), r_init_end = ys + radius;
         const int r_end = max(min(y1 - 1, ylast), ys) + radius;
-        uint32_t acc[N];
+        uint32_t acc[N], outp[N];
+        uint32_t* outaddr = sinkp;
 #pragma unroll
-        for (int k = 0; k < N; k++) acc[k] = 0;
+        for (int k = 0; k < N; k++) acc[k] = outp[k] = 0;
         prefetch(r_begin, 0);
         bt_store(r_begin);
         for (int ry = r_begin; ry <= r_end; ry++) {
             // pix[ry & 1] complete; its previous contents (row ry-2) were consumed before the last
             // barrier.  LDS only: __syncthreads() would also wait for the prefetch in flight (vmcnt(0)).
             lds_barrier();
+            // The row finished in the previous trip is stored here, at the top of the next one, and unconditionally (a thread
+            // with nothing to write - warm-up rows, halo columns - stores to its sink slot).  That keeps the vector memory
+            // operations in flight at the loop's entry and at its back edge the same (the prefetch only) and none of them
+            // behind a branch, so the compiler counts them exactly: the wait for the prefetched operands below is vmcnt(1)
+            // and leaves this store in flight.  With the store at the end of the trip behind its condition the wait was
+            // vmcnt(0) and every row paid a write round trip (27.1 -> ... ms per 1024 C2 frames).
+            store_regs<N>(outaddr, outp);
             uint32_t v[TAPS][N];
             const uint32_t* pw = mypix + (ry & 1) * (NCOL * D2);
             if (j < TX) {
 #pragma unroll
                 for (int t = 0; t < TAPS; t++) load_regs<N>(pw + t * 16 * N, v[t]);
             }
-            if (ry < r_end) bt_store(ry + 1);
+            bt_store(ry + 1);   // also after the last row (row clamped, result unused): no vector memory operation of the loop sits behind a branch
             if (j < TX) {
                 uint32_t hs[N];
 #pragma unroll
@@ -457,13 +467,11 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
                 }
             }
             const int y = ry - radius;
-            if (ry >= r_init_end && y >= y0 && colok) {
-                uint32_t out[N];
 #pragma unroll
-                for (int k = 0; k < N; k++) out[k] = acc[k] + P2P2;
-                store_regs<N>(Cout + (size_t)y * rowN, out);
-            }
+            for (int k = 0; k < N; k++) outp[k] = acc[k] + P2P2;
+            outaddr = (ry >= r_init_end && y >= y0 && colok) ? Cout + (size_t)y * rowN : sinkp;
         }
+        store_regs<N>(outaddr, outp);
         // the bottom `radius` rows repeat the last computed row (costs.cu:279-282), or hold P2
         for (int y = max(y0, ylast + 1); y < y1; y++) {
             uint32_t out[N];

@@ -56,7 +56,7 @@ struct SweepArgs {
     unsigned long long* handoff;   // [n_groups][n_bands - 1][ho_px + 1][REC / 2]: band-boundary records (+1 dummy)
     unsigned int* progress;        // [n_groups][n_bands]: stream pixels exported so far (zeroed before the launch)
     unsigned int* error;           // host-visible: set when a bounded wait ran out
-    uint32_t* sink;                // [gridDim.x * blockDim.x * 4] u32: target of the stores of inactive steps
+    uint32_t* sink;                // [gridDim.x * blockDim.x * N] u32: target of the stores of inactive steps
     int W1, H, W;
     int col0, min_disp;            // first computable column; minDisparity (EXT): stored disparity = (index + min_disp) * 16 + sub-pixel
     uint32_t P1P1, P2P2;
@@ -162,6 +162,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     uint2* const recg = a.rec + (size_t)f0 * H * a.W;
     const uint32_t rowoff = (uint32_t)yp * W1 * PXW + q * N;
     const uint32_t P1P1 = a.P1P1, P2P2 = a.P2P2;
+    uint32_t* const sinkp = a.sink + ((size_t)blockIdx.x * NTHR + tid) * N;
 
     if (tid == 0) (*abortp) = 0;
     // Band 0 has no row above: its import ring is never written, so fill it once with the record
@@ -230,7 +231,12 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     // service wave never share a basic block, so each body is straight-line code for the scheduler.
     if (compute) {
 #pragma unroll
-        for (int j = 0; j < SW_DEPTH; j++) issue(cb[j], sb[j], offq[j], recq[j], actq[j]);
+        for (int j = 0; j < SW_DEPTH; j++) {
+            // sweep 1: the loop is entered with the sequence of vector memory operations in flight that its back edge
+            // carries (a store between the loads), so that the compiler's wait counts stay exact
+            if (!SECOND && j > 0) store_regs<N>(sinkp, r0);
+            issue(cb[j], sb[j], offq[j], recq[j], actq[j]);
+        }
         SW_PROF(unsigned long long pacc[4] = {0, 0, 0, 0};)
         for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
             if ((*abortp) != 0) break;
@@ -330,7 +336,10 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     for (int k = 0; k < N; k++) sp[k] = snew[k];
                     sp_rq = active ? recq[j] : 0xFFFFFFFFu;
                 } else {
-                    if (active) store_regs<N>(Sg + offq[j], snew);
+                    // Unconditional (an inactive step writes to the thread's own sink slot): behind a branch the compiler
+                    // cannot count this store, assumes it away and makes the next step's wait for its C load
+                    // (s_waitcnt vmcnt) cover this store as well - a write round trip exposed in every step.
+                    store_regs<N>(active ? Sg + offq[j] : sinkp, snew);
                 }
                 x++;
                 x = x == W1 ? 0 : x;
