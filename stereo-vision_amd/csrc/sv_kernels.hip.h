@@ -1325,40 +1325,54 @@ __global__ __launch_bounds__(64) void k_fgs_hpass(float* __restrict__ cur, const
                                                    int rw, int rh, int K, float lambda) {
     const int img = blockIdx.y, f = img / K;
     const int row = blockIdx.x * FGS_T + threadIdx.x;
-    const bool rowok = row < rh;
-    const int rr = min(row, rh - 1);   // rows past the end repeat the last row (never written back)
-    float* curR = cur + ((size_t)img * rh + rr) * rw;
-    float* tmpR = tmp + ((size_t)img * rh + rr) * rw;
-    const float* whR = wh + ((size_t)f * rh + rr) * rw;
-    const int ng = rw / 4;   // full groups of four samples; the last rw % 4 samples go one by one
+    // No barrier in this kernel: lanes past the last row leave, and every store below is unconditional.
+    if (row >= rh) return;
+    float* curR = cur + ((size_t)img * rh + row) * rw;
+    float* tmpR = tmp + ((size_t)img * rh + row) * rw;
+    const float* whR = wh + ((size_t)f * rh + row) * rw;
+    const int ng = rw / 4;        // full groups of four samples; the last rw % 4 samples go one by one
+    const int nblk = ng / FGS_PD; // blocks of FGS_PD groups, each group with registers of its own; the last ng % FGS_PD groups go one by one
+    // How the prefetch survives the compiler: a wait for a load is emitted as "all but the n youngest vector memory
+    // operations done", with n counted along every path into the wait and the smallest taken.  So (1) no load or store
+    // of the loops sits behind a condition, (2) the groups in flight keep their registers (a rotation by copies would
+    // have to wait for the loads it copies), and (3) the loop is entered with at least as many operations behind the
+    // first group's loads as its back edge carries: the prologue stores every group it loaded back unchanged.
     float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
-    {
+    if (nblk > 0) {
         float c[FGS_PD][4], w[FGS_PD][4];
 #pragma unroll
-        for (int p = 0; p < FGS_PD; p++) {
-            const int g = min(p, max(ng - 1, 0));
-            if (ng > 0) { fgs_ld4(curR + 4 * g, c[p]); fgs_ld4(whR + 4 * g, w[p]); }
+        for (int p = 0; p < FGS_PD; p++) { fgs_ld4(curR + 4 * p, c[p]); fgs_ld4(whR + 4 * p, w[p]); }
+#pragma unroll
+        for (int p = 0; p < FGS_PD; p++) { fgs_st4(curR + 4 * p, c[p]); fgs_st4(tmpR + 4 * p, w[p]); }   // cur unchanged, tmp is scratch
+        for (int blk = 0; blk < nblk; blk++) {
+#pragma unroll
+            for (int p = 0; p < FGS_PD; p++) {
+                const int g = blk * FGS_PD + p;
+                float tt[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) fgs_step(w[p][u], c[p][u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
+                fgs_st4(curR + 4 * g, c[p]);
+                fgs_st4(tmpR + 4 * g, tt);
+                const int gn = min(g + FGS_PD, ng - 1);   // past the last block: an unused, in-bounds prefetch
+                fgs_ld4(curR + 4 * gn, c[p]);
+                fgs_ld4(whR + 4 * gn, w[p]);
+            }
         }
-        for (int g = 0; g < ng; g++) {
-            float cc[4], ww[4], tt[4];
+    }
+    for (int g = nblk * FGS_PD; g < ng; g++) {
+        float cc[4], ww[4], tt[4];
+        fgs_ld4(curR + 4 * g, cc);
+        fgs_ld4(whR + 4 * g, ww);
 #pragma unroll
-            for (int u = 0; u < 4; u++) { cc[u] = c[0][u]; ww[u] = w[0][u]; }
-#pragma unroll
-            for (int p = 0; p + 1 < FGS_PD; p++)
-#pragma unroll
-                for (int u = 0; u < 4; u++) { c[p][u] = c[p + 1][u]; w[p][u] = w[p + 1][u]; }
-            const int gn = min(g + FGS_PD, ng - 1);   // past the end: an unused, in-bounds prefetch
-            fgs_ld4(curR + 4 * gn, c[FGS_PD - 1]);
-            fgs_ld4(whR + 4 * gn, w[FGS_PD - 1]);
-#pragma unroll
-            for (int u = 0; u < 4; u++) fgs_step(ww[u], cc[u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
-            if (rowok) { fgs_st4(curR + 4 * g, cc); fgs_st4(tmpR + 4 * g, tt); }
-        }
-        for (int j = 4 * ng; j < rw; j++) {
-            float cc = curR[j], tt;
-            fgs_step(whR[j], cc, tt, lambda, coef_prev, prev_cur, prev_tmp);
-            if (rowok) { curR[j] = cc; tmpR[j] = tt; }
-        }
+        for (int u = 0; u < 4; u++) fgs_step(ww[u], cc[u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
+        fgs_st4(curR + 4 * g, cc);
+        fgs_st4(tmpR + 4 * g, tt);
+    }
+    for (int j = 4 * ng; j < rw; j++) {
+        float cc = curR[j], tt;
+        fgs_step(whR[j], cc, tt, lambda, coef_prev, prev_cur, prev_tmp);
+        curR[j] = cc;
+        tmpR[j] = tt;
     }
     // this lane reads back what it has just written
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1367,33 +1381,39 @@ __global__ __launch_bounds__(64) void k_fgs_hpass(float* __restrict__ cur, const
     float next = prev_cur;
     for (int j = rw - 2; j >= 4 * ng; j--) {
         next = curR[j] - tmpR[j] * next;
-        if (rowok) curR[j] = next;
+        curR[j] = next;
     }
-    if (ng > 0) {
-        float c[FGS_PD][4], t[FGS_PD][4];
+    auto back4 = [&](int g, float (&cc)[4], const float (&tt)[4]) {
 #pragma unroll
-        for (int p = 0; p < FGS_PD; p++) {
-            const int g = max(ng - 1 - p, 0);
-            fgs_ld4(curR + 4 * g, c[p]);
-            fgs_ld4(tmpR + 4 * g, t[p]);
+        for (int u = 3; u >= 0; u--) {
+            next = (4 * g + u == rw - 1) ? cc[u] : cc[u] - tt[u] * next;
+            cc[u] = next;
         }
-        for (int g = ng - 1; g >= 0; g--) {
-            float cc[4], tt[4];
+    };
+    for (int g = ng - 1; g >= nblk * FGS_PD; g--) {
+        float cc[4], tt[4];
+        fgs_ld4(curR + 4 * g, cc);
+        fgs_ld4(tmpR + 4 * g, tt);
+        back4(g, cc, tt);
+        fgs_st4(curR + 4 * g, cc);
+    }
+    if (nblk > 0) {
+        float c[FGS_PD][4], t[FGS_PD][4];
+        const int gtop = nblk * FGS_PD - 1;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { cc[u] = c[0][u]; tt[u] = t[0][u]; }
+        for (int p = 0; p < FGS_PD; p++) { fgs_ld4(curR + 4 * (gtop - p), c[p]); fgs_ld4(tmpR + 4 * (gtop - p), t[p]); }
 #pragma unroll
-            for (int p = 0; p + 1 < FGS_PD; p++)
+        for (int p = 0; p < FGS_PD; p++) fgs_st4(curR + 4 * (gtop - p), c[p]);   // unchanged
+        for (int blk = 0; blk < nblk; blk++) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) { c[p][u] = c[p + 1][u]; t[p][u] = t[p + 1][u]; }
-            const int gn = max(g - FGS_PD, 0);
-            fgs_ld4(curR + 4 * gn, c[FGS_PD - 1]);
-            fgs_ld4(tmpR + 4 * gn, t[FGS_PD - 1]);
-#pragma unroll
-            for (int u = 3; u >= 0; u--) {
-                next = (4 * g + u == rw - 1) ? cc[u] : cc[u] - tt[u] * next;
-                cc[u] = next;
+            for (int p = 0; p < FGS_PD; p++) {
+                const int g = gtop - blk * FGS_PD - p;
+                back4(g, c[p], t[p]);
+                fgs_st4(curR + 4 * g, c[p]);
+                const int gn = max(g - FGS_PD, 0);
+                fgs_ld4(curR + 4 * gn, c[p]);
+                fgs_ld4(tmpR + 4 * gn, t[p]);
             }
-            if (rowok) fgs_st4(curR + 4 * g, cc);
         }
     }
 }
@@ -1487,82 +1507,103 @@ __global__ __launch_bounds__(64) void k_fgs_hpass_tiles(float* __restrict__ cur,
 }
 
 // Column solves: one lane per column, rows walked in order (coalesced across the wave), FGS_V rows per trip with
-// the loads of FGS_VD trips in flight ahead of the solve chain.
-constexpr int FGS_V = 8, FGS_VD = 3;
+// the loads of FGS_VD trips in flight ahead of the solve chain.  As in k_fgs_hpass the trips in flight keep their
+// registers, no load or store of the main loops sits behind a condition, and the prologue stores what it loaded back
+// unchanged, so that the compiler's wait counts keep the prefetch alive (see there).
+constexpr int FGS_V = 8, FGS_VD = 3;   // (8, 2), (4, 3), (4, 6), (6, 4) and FGS_PD 2 .. 8 measured within 6 % of this
 __global__ __launch_bounds__(64) void k_fgs_vpass(float* __restrict__ cur, const float* __restrict__ wv, float* __restrict__ tmp,
                                                    int rw, int rh, int K, float lambda) {
-    const int j = min((int)(blockIdx.x * blockDim.x + threadIdx.x), rw - 1);  // surplus lanes repeat the last column
+    const int j = min((int)(blockIdx.x * blockDim.x + threadIdx.x), rw - 1);  // surplus lanes repeat the last column (same wave: same values)
     const int img = blockIdx.y, f = img / K;
     float* curI = cur + (size_t)img * rh * rw + j;
     float* tmpI = tmp + (size_t)img * rh * rw + j;
     const float* wvI = wv + (size_t)f * rh * rw + j;
+    const int ntrip = rh / FGS_V;        // full trips of FGS_V rows; the last rh % FGS_V rows go one by one
+    const int nblk = ntrip / FGS_VD;     // blocks of FGS_VD trips with registers of their own; the other full trips go one by one
     float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
-    float cn[FGS_VD][FGS_V], wn[FGS_VD][FGS_V];
-#pragma unroll
-    for (int p = 0; p < FGS_VD; p++)
+    auto ld_trip = [&](const float* a, const float* b2, int t, float (&x)[FGS_V], float (&y)[FGS_V]) {
 #pragma unroll
         for (int u = 0; u < FGS_V; u++) {
-            const size_t o = (size_t)min(p * FGS_V + u, rh - 1) * rw;
-            cn[p][u] = curI[o];
-            wn[p][u] = wvI[o];
+            const size_t o = (size_t)(t * FGS_V + u) * rw;
+            x[u] = a[o];
+            y[u] = b2[o];
         }
-    for (int i0 = 0; i0 < rh; i0 += FGS_V) {
-        float cc[FGS_V], ww[FGS_V], tt[FGS_V];
-#pragma unroll
-        for (int u = 0; u < FGS_V; u++) { cc[u] = cn[0][u]; ww[u] = wn[0][u]; }
-#pragma unroll
-        for (int p = 0; p + 1 < FGS_VD; p++)
-#pragma unroll
-            for (int u = 0; u < FGS_V; u++) { cn[p][u] = cn[p + 1][u]; wn[p][u] = wn[p + 1][u]; }
+    };
+    auto fwd_trip = [&](int t, float (&c)[FGS_V], const float (&w)[FGS_V]) {
 #pragma unroll
         for (int u = 0; u < FGS_V; u++) {
-            const size_t o = (size_t)min(i0 + FGS_VD * FGS_V + u, rh - 1) * rw;
-            cn[FGS_VD - 1][u] = curI[o];
-            wn[FGS_VD - 1][u] = wvI[o];
+            float tt;
+            fgs_step(w[u], c[u], tt, lambda, coef_prev, prev_cur, prev_tmp);
+            tmpI[(size_t)(t * FGS_V + u) * rw] = tt;
+            curI[(size_t)(t * FGS_V + u) * rw] = c[u];
         }
+    };
+    if (nblk > 0) {
+        float cn[FGS_VD][FGS_V], wn[FGS_VD][FGS_V];
 #pragma unroll
-        for (int u = 0; u < FGS_V; u++)
-            if (i0 + u < rh) {
-                fgs_step(ww[u], cc[u], tt[u], lambda, coef_prev, prev_cur, prev_tmp);
-                tmpI[(size_t)(i0 + u) * rw] = tt[u];
-                curI[(size_t)(i0 + u) * rw] = cc[u];
+        for (int p = 0; p < FGS_VD; p++) ld_trip(curI, wvI, p, cn[p], wn[p]);
+#pragma unroll
+        for (int p = 0; p < FGS_VD; p++)
+#pragma unroll
+            for (int u = 0; u < FGS_V; u++) curI[(size_t)(p * FGS_V + u) * rw] = cn[p][u];   // unchanged
+        for (int blk = 0; blk < nblk; blk++) {
+#pragma unroll
+            for (int p = 0; p < FGS_VD; p++) {
+                const int t = blk * FGS_VD + p;
+                fwd_trip(t, cn[p], wn[p]);
+                ld_trip(curI, wvI, min(t + FGS_VD, ntrip - 1), cn[p], wn[p]);   // past the last block: an unused, in-bounds prefetch
             }
+        }
+    }
+    for (int t = nblk * FGS_VD; t < ntrip; t++) {
+        float c[FGS_V], w[FGS_V];
+        ld_trip(curI, wvI, t, c, w);
+        fwd_trip(t, c, w);
+    }
+    for (int i = ntrip * FGS_V; i < rh; i++) {
+        float c = curI[(size_t)i * rw], tt;
+        fgs_step(wvI[(size_t)i * rw], c, tt, lambda, coef_prev, prev_cur, prev_tmp);
+        tmpI[(size_t)i * rw] = tt;
+        curI[(size_t)i * rw] = c;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // backward: rows rh-2 .. 0 (row rh-1 is final); trips aligned to the same FGS_V grid
+    // backward: row rh-1 is final after the forward sweep (it is stored again unchanged)
     float next = prev_cur;
-    const int ilast = rh - 2;
-    if (ilast < 0) return;
-    int i0 = ilast - ilast % FGS_V;
+    auto back_trip = [&](int t, const float (&c)[FGS_V], const float (&tt)[FGS_V]) {
 #pragma unroll
-    for (int p = 0; p < FGS_VD; p++)
-#pragma unroll
-        for (int u = 0; u < FGS_V; u++) {
-            const size_t o = (size_t)min(max(i0 - p * FGS_V + u, 0), rh - 1) * rw;
-            cn[p][u] = curI[o];
-            wn[p][u] = tmpI[o];
+        for (int u = FGS_V - 1; u >= 0; u--) {
+            const int i = t * FGS_V + u;
+            next = (i == rh - 1) ? c[u] : c[u] - tt[u] * next;
+            curI[(size_t)i * rw] = next;
         }
-    for (; i0 >= 0; i0 -= FGS_V) {
-        float cc[FGS_V], tt[FGS_V];
+    };
+    for (int i = rh - 2; i >= ntrip * FGS_V; i--) {
+        next = curI[(size_t)i * rw] - tmpI[(size_t)i * rw] * next;
+        curI[(size_t)i * rw] = next;
+    }
+    for (int t = ntrip - 1; t >= nblk * FGS_VD; t--) {
+        float c[FGS_V], tt[FGS_V];
+        ld_trip(curI, tmpI, t, c, tt);
+        back_trip(t, c, tt);
+    }
+    if (nblk > 0) {
+        float cn[FGS_VD][FGS_V], tn[FGS_VD][FGS_V];
+        const int ttop = nblk * FGS_VD - 1;
 #pragma unroll
-        for (int u = 0; u < FGS_V; u++) { cc[u] = cn[0][u]; tt[u] = wn[0][u]; }
+        for (int p = 0; p < FGS_VD; p++) ld_trip(curI, tmpI, ttop - p, cn[p], tn[p]);
 #pragma unroll
-        for (int p = 0; p + 1 < FGS_VD; p++)
+        for (int p = 0; p < FGS_VD; p++)
 #pragma unroll
-            for (int u = 0; u < FGS_V; u++) { cn[p][u] = cn[p + 1][u]; wn[p][u] = wn[p + 1][u]; }
+            for (int u = 0; u < FGS_V; u++) curI[(size_t)((ttop - p) * FGS_V + u) * rw] = cn[p][u];   // unchanged
+        for (int blk = 0; blk < nblk; blk++) {
 #pragma unroll
-        for (int u = 0; u < FGS_V; u++) {
-            const size_t o = (size_t)max(i0 - FGS_VD * FGS_V + u, 0) * rw;
-            cn[FGS_VD - 1][u] = curI[o];
-            wn[FGS_VD - 1][u] = tmpI[o];
-        }
-#pragma unroll
-        for (int u = FGS_V - 1; u >= 0; u--)
-            if (i0 + u <= ilast) {
-                next = cc[u] - tt[u] * next;
-                curI[(size_t)(i0 + u) * rw] = next;
+            for (int p = 0; p < FGS_VD; p++) {
+                const int t = ttop - blk * FGS_VD - p;
+                back_trip(t, cn[p], tn[p]);
+                ld_trip(curI, tmpI, max(t - FGS_VD, 0), cn[p], tn[p]);
             }
+        }
     }
 }
 
