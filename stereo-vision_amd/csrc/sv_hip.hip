@@ -470,7 +470,7 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     constexpr int ROWS = 4 * CW, NTHR = (CW + 1) * 64;
     const int D = c->prm.num_disparities, W1 = geo_w1(c->W, c->prm), H = c->H;
     const int n_bands = (H + ROWS - 1) / ROWS;
-    constexpr size_t lds = svk::sweep_lds_bytes<N, CW>();
+    const size_t lds = second ? svk::sweep_lds_bytes<N, CW, true>() : svk::sweep_lds_bytes<N, CW, false>();
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2048 / NTHR) per_cu = 2048 / NTHR;
     if (per_cu < 1) per_cu = 1;

@@ -70,9 +70,17 @@ struct SweepArgs {
 template <int N>
 __host__ __device__ constexpr int sweep_rec_words() { return 3 * 16 * N + 16; }
 // CW = compute waves per workgroup (4 image rows each) + one service wave
-template <int N, int CW>
+// Sweep 2 in the 16-wave shape keeps the finished S of every row's last pixel in LDS for the neighbour fetch of
+// winner-take-all: per row 16 bytes of zeros (the halfword before disparity 0), the 32 N halfwords, 16 bytes of zeros.
+// (Not in the 8-wave shape: its two workgroups per CU have no room for it.)
+template <int N>
+__host__ __device__ constexpr int sweep_nb_words() { return 16 * N + 8; }
+template <int CW, bool SECOND>
+__host__ __device__ constexpr bool sweep_nb_in_lds() { return SECOND && CW == 15; }
+template <int N, int CW, bool SECOND>
 __host__ __device__ constexpr size_t sweep_lds_bytes() {
-    return sizeof(uint32_t) * ((size_t)(2 * (4 * CW + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4);
+    return sizeof(uint32_t) * ((size_t)(2 * (4 * CW + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4 +
+                               (sweep_nb_in_lds<CW, SECOND>() ? (size_t)4 * CW * sweep_nb_words<N>() : 0));
 }
 
 // One SGM path update of one pixel: r = previous L along the path (0 with dd = P2 when the path
@@ -164,6 +172,10 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     const uint32_t P1P1 = a.P1P1, P2P2 = a.P2P2;
     uint32_t* const sinkp = a.sink + ((size_t)blockIdx.x * NTHR + tid) * N;
 
+    constexpr bool NB_LDS = sweep_nb_in_lds<CW, SECOND>();
+    constexpr int NBW = sweep_nb_words<N>();
+    uint32_t* const wrow = abortp + 4 + (NB_LDS && compute ? r * NBW : 0);   // this row's S slot (see sweep_nb_words)
+    if (NB_LDS && compute && q < 8) wrow[q < 4 ? q : PXW + q] = 0u;          // the zeros on both sides of it
     if (tid == 0) (*abortp) = 0;
     // Band 0 has no row above: its import ring is never written, so fill it once with the record
     // of a path start (L = 0, delta = P2) and the first image row needs no special case.
@@ -284,6 +296,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, L1, n1, big0, big15);   // from (x-1, y-1): read two steps ago
                 store_regs<N>(dst + 2 * PXW + q * N, L1);
                 if (SECOND) w_key = wta_stage_key<N, true>(sp, q);
+                if (NB_LDS) store_regs<N>(wrow + 4 + q * N, sp);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], dn, dn_dd, P1P1, L2, n2, big0, big15);               // from (x,   y-1): read last step
                 store_regs<N>(dst + PXW + q * N, L2);
@@ -291,7 +304,15 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, L3, n3, big0, big15);            // from (x+1, y-1): read now
                 store_regs<N>(dst + q * N, L3);
-                if (SECOND) w_nb = wta_stage_neighbours<N, true>(sp, w_key, q);
+                if (NB_LDS) {
+                    // S[best-1] and S[best+1] straight from the row's slot (every lane of the group reads the same two
+                    // halfwords; the zeros around the slot stand for "no such disparity"): 3 vector instructions and 2 LDS
+                    // reads instead of the 28 of the select chain + OR butterfly in registers
+                    const uint16_t* h = reinterpret_cast<const uint16_t*>(wrow) + (w_key & 0xFFu);
+                    w_nb = ((uint32_t)h[7] << 16) | (uint32_t)h[9];
+                } else if (SECOND) {
+                    w_nb = wta_stage_neighbours<N, true>(sp, w_key, q);
+                }
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal: stays in registers
                 sweep_lane_min4(n0, n1, n2, n3);
