@@ -72,15 +72,15 @@ __host__ __device__ constexpr int sweep_rec_words() { return 3 * 16 * N + 16; }
 // CW = compute waves per workgroup (4 image rows each) + one service wave
 // Sweep 2 in the 16-wave shape keeps the finished S of every row's last pixel in LDS for the neighbour fetch of
 // winner-take-all: per row 16 bytes of zeros (the halfword before disparity 0), the 32 N halfwords, 16 bytes of zeros.
-// (Not in the 8-wave shape: its two workgroups per CU have no room for it.)
+// (Not in the 8-wave shape up to D = 128: its two workgroups per CU have no room for it.  Above, one workgroup per CU has.)
 template <int N>
 __host__ __device__ constexpr int sweep_nb_words() { return 16 * N + 8; }
-template <int CW, bool SECOND>
-__host__ __device__ constexpr bool sweep_nb_in_lds() { return SECOND && CW == 15; }
+template <int N, int CW, bool SECOND>
+__host__ __device__ constexpr bool sweep_nb_in_lds() { return SECOND && (CW == 15 || N > 4); }
 template <int N, int CW, bool SECOND>
 __host__ __device__ constexpr size_t sweep_lds_bytes() {
     return sizeof(uint32_t) * ((size_t)(2 * (4 * CW + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4 +
-                               (sweep_nb_in_lds<CW, SECOND>() ? (size_t)4 * CW * sweep_nb_words<N>() : 0));
+                               (sweep_nb_in_lds<N, CW, SECOND>() ? (size_t)4 * CW * sweep_nb_words<N>() : 0));
 }
 
 // One SGM path update of one pixel: r = previous L along the path (0 with dd = P2 when the path
@@ -172,7 +172,8 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     const uint32_t P1P1 = a.P1P1, P2P2 = a.P2P2;
     uint32_t* const sinkp = a.sink + ((size_t)blockIdx.x * NTHR + tid) * N;
 
-    constexpr bool NB_LDS = sweep_nb_in_lds<CW, SECOND>();
+    constexpr bool NB_LDS = sweep_nb_in_lds<N, CW, SECOND>();
+    static_assert(sweep_lds_bytes<N, CW, SECOND>() <= 160 * 1024, "LDS of a CU");
     constexpr int NBW = sweep_nb_words<N>();
     uint32_t* const wrow = abortp + 4 + (NB_LDS && compute ? r * NBW : 0);   // this row's S slot (see sweep_nb_words)
     if (NB_LDS && compute && q < 8) wrow[q < 4 ? q : PXW + q] = 0u;          // the zeros on both sides of it
