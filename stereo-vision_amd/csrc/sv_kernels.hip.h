@@ -529,7 +529,9 @@ __device__ __forceinline__ UniqK make_uniq(int uniq) {
 struct WtaPart {
     uint32_t key;  // minS << 16 | min(hits, 255) << 8 | best d; hits = number of disparities with S < T
     uint32_t nb;   // S[best-1] << 16 | S[best+1] (0 where there is no such disparity)
+    uint32_t m2;   // wta_finish<D, true> only: the smallest S outside best-1 .. best+1 (hits field of key unused)
 };
+typedef uint16_t __attribute__((may_alias)) u16_alias;   // halfword view of LDS words (type-based alias analysis off)
 __device__ __forceinline__ uint32_t wta_threshold(uint32_t minS, UniqK uq) {
     return __umulhi(minS * uq.k + uq.add, uq.magic);
 }
@@ -612,14 +614,16 @@ __device__ __forceinline__ WtaPart wta_reduce(const uint32_t (&s)[N], int q, Uni
     const uint32_t cnt = wta_stage_count<N, false>(s, key, uq);
     const uint32_t nb = wta_stage_neighbours<N, false>(s, key, q);
     // best < 256 and the count only matters up to 4 (at most three positions are exempt): both fit the low half
-    return WtaPart{key | (min(cnt, 255u) << 8), nb};
+    return WtaPart{key | (min(cnt, 255u) << 8), nb, 0u};
 }
 
 // The per-pixel arithmetic on the reduced words (lane-local: k_sweep runs it once per 16 pixels,
 // each lane finishing a different pixel).  D = number of disparities.
 // min_disp (EXT, cv::StereoSGBM minDisparity): the stored disparity is (best + min_disp) * 16 + sub-pixel, "none" is
 // (min_disp - 1) * 16; the raw field stays the cost index (-1 = none).
-template <int D>
+// M2: the uniqueness test as "the smallest S outside best-1 .. best+1 is below T" (w.m2) instead of hits > exempt hits:
+// the same predicate (some S outside the three exempt positions is below T).
+template <int D, bool M2 = false>
 __device__ __forceinline__ uint2 wta_finish(WtaPart w, UniqK uq, int min_disp = 0) {
     const int minS = (int)(w.key >> 16), best = (int)(w.key & 0xFFu);
     const uint32_t cnt = (w.key >> 8) & 0xFFu;
@@ -628,7 +632,7 @@ __device__ __forceinline__ uint2 wta_finish(WtaPart w, UniqK uq, int min_disp = 
     const bool inner = 0 < best && best < D - 1;
     const uint32_t exempt = (uint32_t)((uint32_t)minS < T) + (uint32_t)(best > 0 && (uint32_t)sm < T) +
                             (uint32_t)(best < D - 1 && (uint32_t)sp < T);
-    const bool bad = cnt > exempt;
+    const bool bad = M2 ? w.m2 < T : cnt > exempt;
     // sub-pixel: ((sm - sp)*16 + den) / (2*den), C division (truncation toward zero), |quotient| <= 8.
     // In float without a correction step: floor(|num| / den2) = floor((2|num| + 1) / (2 den2)), whose
     // exact value is at least 1/(2 den2) >= 3.8e-6 away from an integer, while v_rcp_f32 + one

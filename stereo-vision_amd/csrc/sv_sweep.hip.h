@@ -196,7 +196,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
     for (int k = 0; k < N; k++) r0[k] = dn[k] = dr[0][k] = dr[1][k] = 0;
     const UniqK uqk = make_uniq(a.uniq);
-    WtaPart stash = {0u, 0u};              // sweep 2: reduced WTA words of the pixel this lane will finish
+    WtaPart stash = {0u, 0u, 0u};          // sweep 2: reduced WTA words of the pixel this lane will finish
     uint32_t stash_rq = 0xFFFFFFFFu;       // ... and its record index (all ones: nothing kept)
     uint32_t sp[N], sp_rq = 0xFFFFFFFFu;   // sweep 2: finished S of the previous step's pixel and its record index (its WTA runs this step)
 #pragma unroll
@@ -207,6 +207,30 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     const uint32_t rowrec = (uint32_t)yp * a.W + a.col0, frame_px = (uint32_t)H * a.W;
     bool actq[SW_DEPTH];
 
+    // Winner-take-all on the row's LDS copy of the finished S (sweep_nb_words): with the first minimum known (key = minS
+    // << 16 | best), S[best-1] and S[best+1] are two halfword reads (every lane of the group reads the same two; the
+    // zeros around the slot stand for "no such disparity"), and the uniqueness test needs the smallest S outside
+    // best-1 .. best+1: the three positions are overwritten with 0xFFFF (clamped at the ends: best itself is hit again)
+    // and the lane's 2N values read back.  3 + 13 vector instructions instead of 28 + ~24 for the select chain, the OR
+    // butterfly, the threshold division (two quarter-rate multiplies) and the hit count in registers.
+    auto wta_lds_neighbours_mask = [&](uint32_t key, uint32_t& nb, uint32_t (&sm)[N]) {
+        const int best = (int)(key & 0xFFu);
+        u16_alias* const hw = reinterpret_cast<u16_alias*>(wrow);
+        u16_alias* const h = hw + best;   // S[d] is halfword 8 + d of the slot
+        nb = ((uint32_t)h[7] << 16) | (uint32_t)h[9];
+        hw[max(best, 1) + 7] = (uint16_t)0xFFFFu;
+        h[8] = (uint16_t)0xFFFFu;
+        hw[min(best, 32 * N - 2) + 9] = (uint16_t)0xFFFFu;
+        asm volatile("" ::: "memory");    // the read-back below stays behind the three stores
+        load_regs<N>(wrow + 4 + q * N, sm);
+    };
+    auto wta_lds_second_min = [&](auto sched, const uint32_t (&sm)[N]) {
+        uint32_t m = sm[0];
+#pragma unroll
+        for (int k = 1; k < N; k++) m = pk_min(m, sm[k]);
+        m = min(m & 0xFFFFu, m >> 16);
+        return decltype(sched)::value ? row16_min_u32_s(m) : row16_min_u32(m);
+    };
     auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N], uint32_t& off, uint32_t& rq, bool& act) {
         const int xx = min(max(lx, 0), W1 - 1);      // clamped: a load outside the stream reads a valid, unused pixel
         const uint32_t xp = (uint32_t)(SECOND ? W1 - 1 - xx : xx);
@@ -301,19 +325,14 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], dn, dn_dd, P1P1, L2, n2, big0, big15);               // from (x,   y-1): read last step
                 store_regs<N>(dst + PXW + q * N, L2);
-                if (SECOND) w_cnt = wta_stage_count<N, true>(sp, w_key, uqk);
+                uint32_t sm[N];
+                if (NB_LDS) wta_lds_neighbours_mask(w_key, w_nb, sm);
+                else if (SECOND) w_cnt = wta_stage_count<N, true>(sp, w_key, uqk);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, L3, n3, big0, big15);            // from (x+1, y-1): read now
                 store_regs<N>(dst + q * N, L3);
-                if (NB_LDS) {
-                    // S[best-1] and S[best+1] straight from the row's slot (every lane of the group reads the same two
-                    // halfwords; the zeros around the slot stand for "no such disparity"): 3 vector instructions and 2 LDS
-                    // reads instead of the 28 of the select chain + OR butterfly in registers
-                    const uint16_t* h = reinterpret_cast<const uint16_t*>(wrow) + (w_key & 0xFFu);
-                    w_nb = ((uint32_t)h[7] << 16) | (uint32_t)h[9];
-                } else if (SECOND) {
-                    w_nb = wta_stage_neighbours<N, true>(sp, w_key, q);
-                }
+                if (NB_LDS) w_cnt = wta_lds_second_min(std::true_type{}, sm);   // w_cnt carries m2 in this form
+                else if (SECOND) w_nb = wta_stage_neighbours<N, true>(sp, w_key, q);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal: stays in registers
                 sweep_lane_min4(n0, n1, n2, n3);
@@ -334,11 +353,16 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     // pixel it kept (thresholds, sub-pixel division, record) and stores its record:
                     // the lane-local arithmetic runs once per 16 pixels instead of 16-fold redundantly.
                     const bool mine = q == ((tau + j - 1) & 15);   // sp is the pixel of step tau + j - 1
-                    stash.key = mine ? (w_key | (min(w_cnt, 255u) << 8)) : stash.key;
+                    if (NB_LDS) {
+                        stash.key = mine ? w_key : stash.key;
+                        stash.m2 = mine ? w_cnt : stash.m2;
+                    } else {
+                        stash.key = mine ? (w_key | (min(w_cnt, 255u) << 8)) : stash.key;
+                    }
                     stash.nb = mine ? w_nb : stash.nb;
                     stash_rq = mine ? sp_rq : stash_rq;
                     if (j == 0 && (tau & 15) == 0) {               // the pixel just kept was the 16th
-                        if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk, a.min_disp);
+                        if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N, NB_LDS>(stash, uqk, a.min_disp);
                         stash_rq = 0xFFFFFFFFu;
                     }
                 }
@@ -376,13 +400,24 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
             // the pixel of the last step the loop ran (it runs whole groups of SW_DEPTH steps), then the pixels kept since
             // the last 16-step boundary
             const int last_step = -SW_LEAD + SW_DEPTH * ((tau_end + SW_LEAD + SW_DEPTH - 1) / SW_DEPTH) - 1;
-            const uint32_t w_key = wta_stage_key<N, false>(sp, q), w_cnt = wta_stage_count<N, false>(sp, w_key, uqk);
-            const uint32_t w_nb = wta_stage_neighbours<N, false>(sp, w_key, q);
+            const uint32_t w_key = wta_stage_key<N, false>(sp, q);
+            uint32_t w_cnt, w_nb;
             const bool mine = q == (last_step & 15);
-            stash.key = mine ? (w_key | (min(w_cnt, 255u) << 8)) : stash.key;
+            if (NB_LDS) {
+                uint32_t sm[N];
+                store_regs<N>(wrow + 4 + q * N, sp);
+                wta_lds_neighbours_mask(w_key, w_nb, sm);
+                w_cnt = wta_lds_second_min(std::false_type{}, sm);
+                stash.key = mine ? w_key : stash.key;
+                stash.m2 = mine ? w_cnt : stash.m2;
+            } else {
+                w_cnt = wta_stage_count<N, false>(sp, w_key, uqk);
+                w_nb = wta_stage_neighbours<N, false>(sp, w_key, q);
+                stash.key = mine ? (w_key | (min(w_cnt, 255u) << 8)) : stash.key;
+            }
             stash.nb = mine ? w_nb : stash.nb;
             stash_rq = mine ? sp_rq : stash_rq;
-            if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N>(stash, uqk, a.min_disp);
+            if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N, NB_LDS>(stash, uqk, a.min_disp);
         }
         SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
     } else {
