@@ -160,14 +160,19 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    dev = local_rank
+    if os.environ.get("SV_BENCH_SHARE_DEVICE") == "1":
+        # rehearsal of the world > 1 branch on a box with fewer GPUs than ranks (the ranks then share devices; RCCL refuses
+        # that and the barrier goes over gloo): exercises rank seeds, the barrier and the max-over-ranks rule, not scaling
+        dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     backend = None
     if world > 1:
         # RCCL carries only the timing barrier and the max-over-ranks; if it cannot come up on this node the
         # same two operations go over gloo (host tensors) rather than losing the measurement
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
             probe = torch.zeros(1, device="cuda")
             dist.all_reduce(probe)
             torch.cuda.synchronize()
@@ -190,7 +195,7 @@ def main():
     pairs = [synth.stereo_pair(seed0 + i, W, H, D) for i in range(n_distinct)]
     lefts = [p[0] for p in pairs]
     rights = [p[1] for p in pairs]
-    m = svhip.Matcher(W, H, params, device=local_rank)
+    m = svhip.Matcher(W, H, params, device=dev)
     while True:   # the volumes of the default batch take 140 of the 288 GB: on a card with less to give, halve it
         try:
             m.set_batch(B)
