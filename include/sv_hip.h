@@ -193,7 +193,7 @@ int sv_compute_gray_dev(sv_ctx* ctx, const uint8_t* left_dev, const uint8_t* rig
 
 /* Frame batching.  Stereo pairs are independent, so one launch can
  * carry many of them: sv_set_batch sizes the internal volumes for up to
- * max_frames pairs (288 GB of HBM hold hundreds of 640x480 D=128 frames) and
+ * max_frames pairs, 1 .. 2048 (288 GB of HBM hold 2000 640x480 D=128 frames) and
  * sv_compute_gray_batch_dev runs n_frames dense-packed pairs ([n][H][W] u8 in,
  * [n][H][W] int16 out) through the same kernels with the frame index as a grid
  * dimension.  No counterpart in the reference (one frame, static buffers,

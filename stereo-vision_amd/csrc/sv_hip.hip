@@ -998,7 +998,7 @@ int sv_compute_gray_dev(sv_ctx* c, const uint8_t* left_dev, const uint8_t* right
 
 int sv_set_batch(sv_ctx* c, int max_frames) {
     if (!c) return SV_ERR_INVALID_ARG;
-    if (max_frames < 1 || max_frames > 1024) return fail(c, SV_ERR_INVALID_ARG, "batch must be in [1,1024] (got %d)", max_frames);
+    if (max_frames < 1 || max_frames > 2048) return fail(c, SV_ERR_INVALID_ARG, "batch must be in [1,2048] (got %d)", max_frames);
     DevGuard g(c->device);
     if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
     if (max_frames != c->batch) HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -115,3 +115,28 @@ def test_too_wide_is_rejected(gpu):
     with pytest.raises(svhip.SvError) as e:
         svhip.Matcher(40001, 8, svhip.default_params(32, 8))
     assert e.value.code == -1   # SV_ERR_INVALID_ARG
+
+
+def test_batch_above_1024_small_frames(gpu):
+    """sv_set_batch accepts up to 2048 pairs: 1500 small pairs in one launch (fused sweeps, many frames per workgroup
+    pipeline), 6 distinct pairs looped, every frame against the oracle's result for its pair."""
+    import torch
+    W, H, D, nb = 112, 40, 32, 1500
+    ph, po = _params(D, 8)
+    pairs = [synth.stereo_pair(8100 + i, W, H, D) for i in range(6)]
+    refs = [svref.sgbm(p[0], p[1], po) for p in pairs]
+    lt = torch.from_numpy(np.stack([pairs[i % 6][0] for i in range(nb)])).cuda()
+    rt = torch.from_numpy(np.stack([pairs[i % 6][1] for i in range(nb)])).cuda()
+    out = torch.full((nb, H, W), 12345, dtype=torch.int16, device="cuda")
+    m = svhip.Matcher(W, H, ph)
+    m.set_batch(nb)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    m.synchronize()
+    assert m.last_aggregation() == (2, 2)   # two launches, both fused sweeps
+    got = out.cpu().numpy()
+    for i in range(nb):
+        assert np.array_equal(got[i], refs[i % 6]), "frame %d" % i
+    with pytest.raises(svhip.SvError):
+        m.set_batch(2049)
+    m.close()
