@@ -751,9 +751,10 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         // pay the pipeline fill once per launch: they win once every pipeline has a frame to stream
         // (measured at 640x480 D=128 on 256 CUs = 32 pipelines: 24 frames 3000 vs 3060 frames/s for the
         // per-path kernels, 32 frames 3810 vs 3100), below that the per-path kernels are faster.
-        // (with the 8-wave form chosen for small launches: from 3/4 of its pipelines, 21 frames there)
+        // (with the 8-wave form chosen for small launches: from 5/8 of its pipelines, 18 frames there: 16 frames 2960 vs
+        // 3090 frames/s for the per-path kernels, 20 frames 3540 vs 3020; scratch/perf_thresh.py)
         const int sw_pipes = sweep_pipes(c, sweep_cw_for(c, nb));
-        const int sw_auto = (D > 128 || c->sweep_cw) ? sw_pipes : (3 * sweep_pipes(c, 7) + 3) / 4;
+        const int sw_auto = (D > 128 || c->sweep_cw) ? sw_pipes : (5 * sweep_pipes(c, 7) + 7) / 8;
         const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : sw_auto;
         const bool sweep_ok = !c->debug && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= sw_min);
         const bool sw1 = sweep_ok && (p.path_mask & 0x0Fu) == 0x0Fu;
