@@ -572,6 +572,18 @@ __device__ __forceinline__ uint32_t wta_stage_key(const uint32_t (&s)[N], int q)
     key += (uint32_t)(q * 2 * N);   // 2N - 1 + dbase < 256: no carry into S
     return SCHED ? row16_min_u32_s(key) : row16_min_u32(key);
 }
+// The lane-local part of A alone (k_sweep: the 16 lanes of a row leave their keys in LDS and one lane of the service wave
+// takes the minimum of the 16).
+template <int N>
+__device__ __forceinline__ uint32_t wta_lane_key(const uint32_t (&s)[N], int q) {
+    uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        key = min(key, (s[k] << 16) | (uint32_t)(2 * k));
+        key = min(key, (s[k] & 0xFFFF0000u) | (uint32_t)(2 * k + 1));
+    }
+    return key + (uint32_t)(q * 2 * N);
+}
 // B: uniqueness: no S outside best-1..best+1 may be below T.  Every S lies in [0, 32767], so with T
 // clamped to 32768 "S < T" is the sign of the 16-bit difference: count the hits over all disparities;
 // wta_finish compares the count with the hits among the three exempt positions.
@@ -645,6 +657,45 @@ __device__ __forceinline__ uint2 wta_finish(WtaPart w, UniqK uq, int min_disp = 
     const bool ok = minS < 32767 && !bad;  // minS == 32767: every S saturated, no minimum
     const int dv = ok ? (best + min_disp) * 16 + sub : (min_disp - 1) * 16, rw = ok ? best : -1;
     return make_uint2(((uint32_t)dv & 0xFFFFu) | ((uint32_t)rw << 16), (uint32_t)minS);
+}
+
+// Winner-take-all of one pixel by ONE lane, from the pixel's LDS slot (sv_sweep.hip.h, sweep_wta_words): slot[0 .. 16N) = S as
+// 32 N halfwords in disparity order, slot[16N .. 16N + 16) = the 16 lane keys.  First minimum = the smallest key; S[best-1]
+// and S[best+1] are two halfword reads; the uniqueness test needs the smallest S outside best-1 .. best+1: the (one or two)
+// lanes that hold those positions are struck from the keys and the three positions from S (all ones), then it is the
+// minimum of the remaining keys and of the two struck lanes' 2N values.  The slot is consumed (the row rewrites all of it).
+template <int N>
+__device__ __forceinline__ uint2 wta_from_slot(uint32_t* slot, UniqK uq, int min_disp) {
+    constexpr int D = 32 * N;
+    uint32_t k16[16];
+    load_regs<16>(slot + 16 * N, k16);
+    uint32_t key = k16[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) key = min(key, k16[i]);
+    const int best = min((int)(key & 0xFFu), D - 1);   // (the clamp only matters for a slot nobody has written yet)
+    const int bm = max(best - 1, 0), bp = min(best + 1, D - 1);
+    u16_alias* const hw = reinterpret_cast<u16_alias*>(slot);
+    const uint32_t nb = ((uint32_t)hw[bm] << 16) | (uint32_t)hw[bp];
+    const int qa = bm / (2 * N), qb = bp / (2 * N);
+    asm volatile("" ::: "memory");
+    slot[16 * N + qa] = 0xFFFFFFFFu;
+    slot[16 * N + qb] = 0xFFFFFFFFu;
+    hw[bm] = (uint16_t)0xFFFFu;
+    hw[best] = (uint16_t)0xFFFFu;
+    hw[bp] = (uint16_t)0xFFFFu;
+    asm volatile("" ::: "memory");    // the reads below stay behind the stores
+    load_regs<16>(slot + 16 * N, k16);
+    uint32_t ca[N], cb[N];
+    load_regs<N>(slot + qa * N, ca);
+    load_regs<N>(slot + qb * N, cb);
+    uint32_t mo = k16[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mo = min(mo, k16[i]);
+    uint32_t mt = pk_min(ca[0], cb[0]);
+#pragma unroll
+    for (int k = 1; k < N; k++) mt = pk_min(mt, pk_min(ca[k], cb[k]));
+    const uint32_t m2 = min(min(mt & 0xFFFFu, mt >> 16), mo >> 16);
+    return wta_finish<D, true>(WtaPart{key, nb, m2}, uq, min_disp);
 }
 
 template <int N>

@@ -34,7 +34,7 @@
 
 namespace svk {
 
-constexpr int SW_RING = 16;   // pixels in the import / export rings
+constexpr int SW_RING = 8;    // pixels in the import / export rings (a record is written <= 3 steps before it is read)
 constexpr int SW_LEAD = 32;   // loop steps before stream pixel 0 (service pipeline warm-up), multiple of 4
 #ifndef SV_SW_DEPTH
 #define SV_SW_DEPTH 2
@@ -70,17 +70,16 @@ struct SweepArgs {
 template <int N>
 __host__ __device__ constexpr int sweep_rec_words() { return 3 * 16 * N + 16; }
 // CW = compute waves per workgroup (4 image rows each) + one service wave
-// Sweep 2 in the 16-wave shape keeps the finished S of every row's last pixel in LDS for the neighbour fetch of
-// winner-take-all: per row 16 bytes of zeros (the halfword before disparity 0), the 32 N halfwords, 16 bytes of zeros.
-// (Not in the 8-wave shape up to D = 128: its two workgroups per CU have no room for it.  Above, one workgroup per CU has.)
+// Sweep 2 hands every finished pixel to the service wave for winner-take-all through a per-row LDS slot, double-buffered
+// by the step's parity: the 32 N halfwords of S in disparity order, then the 16 lanes' local first-minimum keys
+// (S << 16 | d), then 4 words of padding: a row stride of 16 N + 20 words is an odd multiple of 4, so the 16-byte reads of
+// the service wave (one lane per row, all lanes at the same offset of their row) spread over all banks.
 template <int N>
-__host__ __device__ constexpr int sweep_nb_words() { return 16 * N + 8; }
-template <int N, int CW, bool SECOND>
-__host__ __device__ constexpr bool sweep_nb_in_lds() { return SECOND && (CW == 15 || N > 4); }
+__host__ __device__ constexpr int sweep_wta_words() { return 16 * N + 20; }
 template <int N, int CW, bool SECOND>
 __host__ __device__ constexpr size_t sweep_lds_bytes() {
     return sizeof(uint32_t) * ((size_t)(2 * (4 * CW + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4 +
-                               (sweep_nb_in_lds<N, CW, SECOND>() ? (size_t)4 * CW * sweep_nb_words<N>() : 0));
+                               (SECOND ? (size_t)2 * 4 * CW * sweep_wta_words<N>() : 0));
 }
 
 // One SGM path update of one pixel: r = previous L along the path (0 with dd = P2 when the path
@@ -172,11 +171,13 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     const uint32_t P1P1 = a.P1P1, P2P2 = a.P2P2;
     uint32_t* const sinkp = a.sink + ((size_t)blockIdx.x * NTHR + tid) * N;
 
-    constexpr bool NB_LDS = sweep_nb_in_lds<N, CW, SECOND>();
     static_assert(sweep_lds_bytes<N, CW, SECOND>() <= 160 * 1024, "LDS of a CU");
-    constexpr int NBW = sweep_nb_words<N>();
-    uint32_t* const wrow = abortp + 4 + (NB_LDS && compute ? r * NBW : 0);   // this row's S slot (see sweep_nb_words)
-    if (NB_LDS && compute && q < 8) wrow[q < 4 ? q : PXW + q] = 0u;          // the zeros on both sides of it
+    // sweep 2: winner-take-all slots [2][SW_ROWS][WSTR] (sweep_wta_words): written by a row's lanes, read by lane `row` of the service wave
+    constexpr int WSTR = sweep_wta_words<N>();
+    uint32_t* const wta0 = abortp + 4;
+    uint32_t* const wrow = wta0 + (compute ? r : min(lane, SW_ROWS - 1)) * WSTR;   // this row's slot of parity 0
+    if (SECOND)
+        for (int i = tid; i < 2 * SW_ROWS * WSTR; i += NTHR) wta0[i] = 0u;        // well-formed keys (best = 0) before the first real ones
     if (tid == 0) (*abortp) = 0;
     // Band 0 has no row above: its import ring is never written, so fill it once with the record
     // of a path start (L = 0, delta = P2) and the first image row needs no special case.
@@ -196,46 +197,18 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
     for (int k = 0; k < N; k++) r0[k] = dn[k] = dr[0][k] = dr[1][k] = 0;
     const UniqK uqk = make_uniq(a.uniq);
-    WtaPart stash = {0u, 0u, 0u};          // sweep 2: reduced WTA words of the pixel this lane will finish
-    uint32_t stash_rq = 0xFFFFFFFFu;       // ... and its record index (all ones: nothing kept)
-    uint32_t sp[N], sp_rq = 0xFFFFFFFFu;   // sweep 2: finished S of the previous step's pixel and its record index (its WTA runs this step)
+    uint32_t sp[N];   // sweep 2: finished S of the previous step's pixel (goes to the service wave's slot during this step)
 #pragma unroll
     for (int k = 0; k < N; k++) sp[k] = 0;
     const uint32_t big0 = q == 0 ? 0x7FFF7FFFu : 0u, big15 = q == 15 ? 0x7FFF7FFFu : 0u;  // see sweep_path
-    uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH], recq[SW_DEPTH];
-    uint32_t lrbase = 0;                             // index of frame lfi's first WTA record
-    const uint32_t rowrec = (uint32_t)yp * a.W + a.col0, frame_px = (uint32_t)H * a.W;
+    uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH];
+    const uint32_t frame_px = (uint32_t)H * a.W;
     bool actq[SW_DEPTH];
 
-    // Winner-take-all on the row's LDS copy of the finished S (sweep_nb_words): with the first minimum known (key = minS
-    // << 16 | best), S[best-1] and S[best+1] are two halfword reads (every lane of the group reads the same two; the
-    // zeros around the slot stand for "no such disparity"), and the uniqueness test needs the smallest S outside
-    // best-1 .. best+1: the three positions are overwritten with 0xFFFF (clamped at the ends: best itself is hit again)
-    // and the lane's 2N values read back.  3 + 13 vector instructions instead of 28 + ~24 for the select chain, the OR
-    // butterfly, the threshold division (two quarter-rate multiplies) and the hit count in registers.
-    auto wta_lds_neighbours_mask = [&](uint32_t key, uint32_t& nb, uint32_t (&sm)[N]) {
-        const int best = (int)(key & 0xFFu);
-        u16_alias* const hw = reinterpret_cast<u16_alias*>(wrow);
-        u16_alias* const h = hw + best;   // S[d] is halfword 8 + d of the slot
-        nb = ((uint32_t)h[7] << 16) | (uint32_t)h[9];
-        hw[max(best, 1) + 7] = (uint16_t)0xFFFFu;
-        h[8] = (uint16_t)0xFFFFu;
-        hw[min(best, 32 * N - 2) + 9] = (uint16_t)0xFFFFu;
-        asm volatile("" ::: "memory");    // the read-back below stays behind the three stores
-        load_regs<N>(wrow + 4 + q * N, sm);
-    };
-    auto wta_lds_second_min = [&](auto sched, const uint32_t (&sm)[N]) {
-        uint32_t m = sm[0];
-#pragma unroll
-        for (int k = 1; k < N; k++) m = pk_min(m, sm[k]);
-        m = min(m & 0xFFFFu, m >> 16);
-        return decltype(sched)::value ? row16_min_u32_s(m) : row16_min_u32(m);
-    };
-    auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N], uint32_t& off, uint32_t& rq, bool& act) {
+    auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N], uint32_t& off, bool& act) {
         const int xx = min(max(lx, 0), W1 - 1);      // clamped: a load outside the stream reads a valid, unused pixel
         const uint32_t xp = (uint32_t)(SECOND ? W1 - 1 - xx : xx);
         off = lfbase + rowoff + xp * PXW;
-        rq = lrbase + rowrec + xp;
         act = rowok && lx >= 0 && lfi < nfr;
         load_regs<N>(Cg + off, c);
         if (SECOND) load_regs<N>(Sg + off, s);
@@ -244,7 +217,6 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
         lx = wrap ? 0 : lx;
         lfi += wrap ? 1 : 0;
         lfbase += (wrap && lfi < nfr) ? frame_words : 0u;
-        if (SECOND) lrbase += (wrap && lfi < nfr) ? frame_px : 0u;
     };
 
     // ---- service wave state
@@ -260,6 +232,13 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
         for (int i = 0; i < NQ; i++) ib[j][i] = 0;
 
+    // winner-take-all (sweep 2): lane `row` of the service wave finishes the pixel its row completed two steps earlier
+    const int wrow_i = min(lane, SW_ROWS - 1), wyl = band * SW_ROWS + wrow_i;
+    const bool wrowok = lane < SW_ROWS && wyl < H;
+    int wx = -SW_LEAD - 2 * wrow_i - 4;              // that pixel's position in its frame at step -SW_LEAD (< 0: not started)
+    int wfi = 0;
+    uint32_t wrec = (uint32_t)(H - 1 - min(wyl, H - 1)) * a.W + a.col0;   // record index of the row's first pixel in frame wfi
+
     static_assert(N >= 1 && (N <= 4 || (N <= 8 && CW <= 7)),
                   "k_sweep keeps four paths of D = 32*N disparities in registers: D <= 128 with 16 waves per workgroup (128 "
                   "VGPRs each), D <= 256 with 8 (256 VGPRs each)");
@@ -272,7 +251,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
             // sweep 1: the loop is entered with the sequence of vector memory operations in flight that its back edge
             // carries (a store between the loads), so that the compiler's wait counts stay exact
             if (!SECOND && j > 0) store_regs<N>(sinkp, r0);
-            issue(cb[j], sb[j], offq[j], recq[j], actq[j]);
+            issue(cb[j], sb[j], offq[j], actq[j]);
         }
         SW_PROF(unsigned long long pacc[4] = {0, 0, 0, 0};)
         for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
@@ -312,27 +291,22 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 // LDS store occupies the store path for ~13 cycles per wave, 15 waves x 3 of them bunched in
                 // front of the barrier would leave the VALUs idle for that long; issued early they overlap with
                 // the other waves' arithmetic.  (The row below reads this buffer only after the barrier.)
-                // Sweep 2: winner-take-all of the PREVIOUS step's pixel (its finished S waits in sp) runs in three
-                // stages next to the first three paths: each stage is a dependent chain that ends in a four-step DPP
-                // butterfly, and alone it would spend a third of its issue slots on wait states.
+                // Sweep 2: the finished S of the PREVIOUS step's pixel (it waits in sp) and its lanes' first-minimum keys go to
+                // the row's winner-take-all slot of that step's parity, between the paths for the same reason; the service
+                // wave picks them up in the next step.
                 uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
                                                    : slot + ((j & 1) * (SW_ROWS + 1) + r + 1) * REC;
-                uint32_t w_key = 0, w_cnt = 0, w_nb = 0;
+                uint32_t* const ws = wrow + ((j + 1) & 1) * (SW_ROWS * WSTR);
                 sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, L1, n1, big0, big15);   // from (x-1, y-1): read two steps ago
                 store_regs<N>(dst + 2 * PXW + q * N, L1);
-                if (SECOND) w_key = wta_stage_key<N, true>(sp, q);
-                if (NB_LDS) store_regs<N>(wrow + 4 + q * N, sp);
+                if (SECOND) store_regs<N>(ws + q * N, sp);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], dn, dn_dd, P1P1, L2, n2, big0, big15);               // from (x,   y-1): read last step
                 store_regs<N>(dst + PXW + q * N, L2);
-                uint32_t sm[N];
-                if (NB_LDS) wta_lds_neighbours_mask(w_key, w_nb, sm);
-                else if (SECOND) w_cnt = wta_stage_count<N, true>(sp, w_key, uqk);
+                if (SECOND) ws[PXW + q] = wta_lane_key<N>(sp, q);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, L3, n3, big0, big15);            // from (x+1, y-1): read now
                 store_regs<N>(dst + q * N, L3);
-                if (NB_LDS) w_cnt = wta_lds_second_min(std::true_type{}, sm);   // w_cnt carries m2 in this form
-                else if (SECOND) w_nb = wta_stage_neighbours<N, true>(sp, w_key, q);
                 SW_EARLY_FENCE
                 sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal: stays in registers
                 sweep_lane_min4(n0, n1, n2, n3);
@@ -347,25 +321,6 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 dr_dd[j & 1] = src[3 * PXW + 8];
                 SW_STAMP(T2)
                 dst[3 * PXW + q] = nq + P2P2;
-                if (SECOND) {
-                    // The reductions leave the same three words in all 16 lanes of the row's group;
-                    // lane (pixel's step mod 16) keeps them, and once per 16 steps every lane finishes the
-                    // pixel it kept (thresholds, sub-pixel division, record) and stores its record:
-                    // the lane-local arithmetic runs once per 16 pixels instead of 16-fold redundantly.
-                    const bool mine = q == ((tau + j - 1) & 15);   // sp is the pixel of step tau + j - 1
-                    if (NB_LDS) {
-                        stash.key = mine ? w_key : stash.key;
-                        stash.m2 = mine ? w_cnt : stash.m2;
-                    } else {
-                        stash.key = mine ? (w_key | (min(w_cnt, 255u) << 8)) : stash.key;
-                    }
-                    stash.nb = mine ? w_nb : stash.nb;
-                    stash_rq = mine ? sp_rq : stash_rq;
-                    if (j == 0 && (tau & 15) == 0) {               // the pixel just kept was the 16th
-                        if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N, NB_LDS>(stash, uqk, a.min_disp);
-                        stash_rq = 0xFFFFFFFFu;
-                    }
-                }
                 uint32_t snew[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) {
@@ -380,7 +335,6 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 if (SECOND) {
 #pragma unroll
                     for (int k = 0; k < N; k++) sp[k] = snew[k];
-                    sp_rq = active ? recq[j] : 0xFFFFFFFFu;
                 } else {
                     // Unconditional (an inactive step writes to the thread's own sink slot): behind a branch the compiler
                     // cannot count this store, assumes it away and makes the next step's wait for its C load
@@ -389,35 +343,12 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 }
                 x++;
                 x = x == W1 ? 0 : x;
-                issue(cb[j], sb[j], offq[j], recq[j], actq[j]);
+                issue(cb[j], sb[j], offq[j], actq[j]);
                 SW_STAMP(T3)
                 sweep_barrier();
                 SW_STAMP(T4)
                 SW_PROF(pacc[0] += T1 - T0; pacc[1] += T2 - T1; pacc[2] += T3 - T2; pacc[3] += T4 - T3;)
             }
-        }
-        if (SECOND) {
-            // the pixel of the last step the loop ran (it runs whole groups of SW_DEPTH steps), then the pixels kept since
-            // the last 16-step boundary
-            const int last_step = -SW_LEAD + SW_DEPTH * ((tau_end + SW_LEAD + SW_DEPTH - 1) / SW_DEPTH) - 1;
-            const uint32_t w_key = wta_stage_key<N, false>(sp, q);
-            uint32_t w_cnt, w_nb;
-            const bool mine = q == (last_step & 15);
-            if (NB_LDS) {
-                uint32_t sm[N];
-                store_regs<N>(wrow + 4 + q * N, sp);
-                wta_lds_neighbours_mask(w_key, w_nb, sm);
-                w_cnt = wta_lds_second_min(std::false_type{}, sm);
-                stash.key = mine ? w_key : stash.key;
-                stash.m2 = mine ? w_cnt : stash.m2;
-            } else {
-                w_cnt = wta_stage_count<N, false>(sp, w_key, uqk);
-                w_nb = wta_stage_neighbours<N, false>(sp, w_key, q);
-                stash.key = mine ? (w_key | (min(w_cnt, 255u) << 8)) : stash.key;
-            }
-            stash.nb = mine ? w_nb : stash.nb;
-            stash_rq = mine ? sp_rq : stash_rq;
-            if (stash_rq != 0xFFFFFFFFu) recg[stash_rq] = wta_finish<32 * N, NB_LDS>(stash, uqk, a.min_disp);
         }
         SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
     } else {
@@ -473,6 +404,16 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                         const int done = min(max(p + 1, 0), total_px);
                         if (lane == 0) __hip_atomic_store(flag_out, (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                }
+                if (SECOND) {
+                    // slot of parity t & 1: written by the row during step t - 1 (S of step t - 2); the row writes the other one now
+                    const uint2 rcd = wta_from_slot<N>(wrow + (j & 1) * (SW_ROWS * WSTR), uqk, a.min_disp);
+                    if (wrowok && wx >= 0 && wfi < nfr) recg[wrec + (uint32_t)(W1 - 1 - wx)] = rcd;
+                    wx++;
+                    const bool wrap = wx == W1;
+                    wx = wrap ? 0 : wx;
+                    wfi += wrap ? 1 : 0;
+                    wrec += wrap ? frame_px : 0u;
                 }
                 SW_STAMP(T3)
                 sweep_barrier();
