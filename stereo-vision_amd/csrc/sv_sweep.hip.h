@@ -185,11 +185,23 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
         for (int i = tid; i < SW_RING * REC; i += NTHR) imp[i] = (i % REC) >= 3 * PXW ? P2P2 : 0u;
     __syncthreads();
 
-    // ---- compute rows.  The load cursor (lx, lfi, lfbase) runs SW_DEPTH steps ahead of the compute
-    // cursor x; the offset and the validity of a pixel are computed once, at load time, and queued.
-    int x = -SW_LEAD - 2 * r - 2;                    // compute cursor at step tau = -SW_LEAD (x < 0: not started)
-    int lx = x, lfi = 0;
-    uint32_t lfbase = 0;                             // word offset of frame lfi
+    // ---- compute rows.  One cursor per lane, for the loads, SW_DEPTH steps ahead of the pixel being computed:
+    // lx = its position in the frame row (sweep order), loff = the word offset of that pixel.  A step moves it by one
+    // pixel (dstep words) or, at the end of a frame row, to the first pixel of the same row of the next frame (jump
+    // words); before the stream begins the cursor walks the frames "before frame 0" in modular arithmetic, so it
+    // arrives at pixel 0 of frame 0 by its ordinary wrap, and whether a pixel belongs to the stream at all is one
+    // unsigned compare of its stream index (loads outside the stream read the row's first pixel instead: valid, unused).
+    const int ulane = 2 * r + 2;                                   // stream index of a step's pixel = step - ulane
+    const uint32_t total_eff = rowok ? (uint32_t)total_px : 0u;
+    const int u_first = -SW_LEAD - ulane;                          // stream index of the first load (< 0)
+    const int back = (-u_first + W1 - 1) / W1;                     // frames "before frame 0" it starts in
+    int lx = u_first + back * W1;                                  // in [0, W1)
+    const uint32_t dstep = SECOND ? (uint32_t)-PXW : (uint32_t)PXW;
+    const uint32_t jump = frame_words - (uint32_t)(W1 - 1) * dstep;
+    const uint32_t row0off = rowoff + (SECOND ? (uint32_t)(W1 - 1) * PXW : 0u);   // first pixel of the row in sweep order
+    uint32_t loff = row0off - (uint32_t)back * frame_words + (uint32_t)lx * dstep;
+    // the pixel being computed is SW_DEPTH behind the cursor: it is the first / last of its frame row when lx is
+    const int lx_first = SW_DEPTH % W1, lx_last = (W1 - 1 + SW_DEPTH) % W1;
     // own horizontal L; records of the row above waiting for their turn: the "down" part is used one
     // step after it was read, the "down-right" part two steps after (two registers sets, alternating)
     uint32_t r0[N], dn[N], dr[2][N];
@@ -205,18 +217,15 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     const uint32_t frame_px = (uint32_t)H * a.W;
     bool actq[SW_DEPTH];
 
-    auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N], uint32_t& off, bool& act) {
-        const int xx = min(max(lx, 0), W1 - 1);      // clamped: a load outside the stream reads a valid, unused pixel
-        const uint32_t xp = (uint32_t)(SECOND ? W1 - 1 - xx : xx);
-        off = lfbase + rowoff + xp * PXW;
-        act = rowok && lx >= 0 && lfi < nfr;
+    auto issue = [&](uint32_t (&c)[N], uint32_t (&s)[N], uint32_t& off, bool& act, int step) {
+        act = (uint32_t)(step - ulane) < total_eff;
+        off = act ? loff : row0off;
         load_regs<N>(Cg + off, c);
         if (SECOND) load_regs<N>(Sg + off, s);
         lx++;
         const bool wrap = lx == W1;
         lx = wrap ? 0 : lx;
-        lfi += wrap ? 1 : 0;
-        lfbase += (wrap && lfi < nfr) ? frame_words : 0u;
+        loff += wrap ? jump : dstep;
     };
 
     // ---- service wave state
@@ -251,11 +260,11 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
             // sweep 1: the loop is entered with the sequence of vector memory operations in flight that its back edge
             // carries (a store between the loads), so that the compiler's wait counts stay exact
             if (!SECOND && j > 0) store_regs<N>(sinkp, r0);
-            issue(cb[j], sb[j], offq[j], actq[j]);
+            issue(cb[j], sb[j], offq[j], actq[j], -SW_LEAD + j);
         }
         SW_PROF(unsigned long long pacc[4] = {0, 0, 0, 0};)
         for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
-            if ((*abortp) != 0) break;
+            if ((tau & 15) == 0 && (*abortp) != 0) break;
 #pragma unroll
             for (int j = 0; j < SW_DEPTH; j++) {
                 SW_STAMP(T0)
@@ -268,24 +277,11 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 load_regs<N>(src + q * N, in_dl);
                 uint32_t dd_dl = src[3 * PXW];
                 SW_STAMP(T1)
-                // Path starts (x == 0: horizontal and down-right; x == W1-1: down-left) come up once per
-                // row and frame, so the reset sits behind a wave-uniform branch instead of in every step.
-                const bool st_l = x == 0, st_r = x == W1 - 1;
-                if (__builtin_amdgcn_ballot_w64(st_l || st_r) != 0) {
-                    // In place (tied asm operands): written as plain selects the compiler gives the results new registers
-                    // and pays for it with ~19 v_mov on the common path, where this block is skipped.
-                    const uint32_t kl = st_l ? 0u : 0xFFFFFFFFu, kr = st_r ? 0u : 0xFFFFFFFFu;
-                    const uint32_t pl = st_l ? P2P2 : 0u, pr = st_r ? P2P2 : 0u;   // dd = (dd & k) | p
-#pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        asm volatile("v_and_b32 %0, %0, %1" : "+v"(r0[k]) : "v"(kl));
-                        asm volatile("v_and_b32 %0, %0, %1" : "+v"(dr[j & 1][k]) : "v"(kl));
-                        asm volatile("v_and_b32 %0, %0, %1" : "+v"(in_dl[k]) : "v"(kr));
-                    }
-                    asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(dd0) : "v"(kl), "v"(pl));
-                    asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(dr_dd[j & 1]) : "v"(kl), "v"(pl));
-                    asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(dd_dl) : "v"(kr), "v"(pr));
-                }
+                // Path starts are written into the data, not tested by the reader: the horizontal path's previous L is
+                // cleared after the last pixel of a frame row (end of the step), and the record parts the row below would read across a frame
+                // edge are overwritten with a path start by their producer (below, behind a wave-uniform branch that
+                // touches LDS only: with register updates in it the compiler put ~20 v_mov on the common path).
+                const bool st_l = lx == lx_first, st_r = lx == lx_last;
                 uint32_t L0[N], L1[N], L2[N], L3[N], n0, n1, n2, n3;
                 // Own record for the row below.  Its three L parts leave as soon as each is computed: a 16-byte
                 // LDS store occupies the store path for ~13 cycles per wave, 15 waves x 3 of them bunched in
@@ -321,6 +317,22 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 dr_dd[j & 1] = src[3 * PXW + 8];
                 SW_STAMP(T2)
                 dst[3 * PXW + q] = nq + P2P2;
+                if (__builtin_amdgcn_ballot_w64(st_l || st_r) != 0) {
+                    // pixel 0 of a frame: nothing continues from it down-left into the previous frame's last column
+                    // (part 0, tail words 0-3); last pixel: nothing continues down-right into the next frame's column 0
+                    // (part 2, tail words 8-11).  L = 0, delta = P2: what a reader sees past the image edge.
+                    uint32_t zz[N];
+#pragma unroll
+                    for (int k = 0; k < N; k++) zz[k] = 0u;
+                    if (st_l) {
+                        store_regs<N>(dst + q * N, zz);
+                        if (q < 4) dst[3 * PXW + q] = P2P2;
+                    }
+                    if (st_r) {
+                        store_regs<N>(dst + 2 * PXW + q * N, zz);
+                        if (q >= 8 && q < 12) dst[3 * PXW + q] = P2P2;
+                    }
+                }
                 uint32_t snew[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) {
@@ -329,9 +341,11 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     uint32_t s4 = pk_add_sat15(pk_add_sat15(L0[k], L1[k]), pk_add_sat15(L2[k], L3[k]));
                     if (SECOND) s4 = pk_add_sat15(s4, sb[j][k]);
                     snew[k] = s4;
-                    r0[k] = L0[k];
                 }
-                dd0 = n0 + P2P2;
+                const uint32_t hm = st_r ? 0u : 0xFFFFFFFFu;   // the next pixel starts a frame row: L = 0, delta = P2
+#pragma unroll
+                for (int k = 0; k < N; k++) r0[k] = L0[k] & hm;
+                dd0 = (n0 & hm) + P2P2;
                 if (SECOND) {
 #pragma unroll
                     for (int k = 0; k < N; k++) sp[k] = snew[k];
@@ -341,9 +355,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     // (s_waitcnt vmcnt) cover this store as well - a write round trip exposed in every step.
                     store_regs<N>(active ? Sg + offq[j] : sinkp, snew);
                 }
-                x++;
-                x = x == W1 ? 0 : x;
-                issue(cb[j], sb[j], offq[j], actq[j]);
+                issue(cb[j], sb[j], offq[j], actq[j], tau + j + SW_DEPTH);
                 SW_STAMP(T3)
                 sweep_barrier();
                 SW_STAMP(T4)
@@ -353,9 +365,12 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
         SW_PROF(if (lane == 0) for (int i = 0; i < 4; i++) a.prof[((size_t)blockIdx.x * (CW + 1) + wave) * 4 + i] = pacc[i];)
     } else {
         bool aborted = false;
+#ifdef SW_SVC_PRIO
+        __builtin_amdgcn_s_setprio(SW_SVC_PRIO);
+#endif
         SW_PROF(unsigned long long pacc[4] = {0, 0, 0, 0};)
         for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
-            if ((*abortp) != 0) { aborted = true; break; }
+            if ((tau & 15) == 0 && (*abortp) != 0) { aborted = true; break; }   // same test, same steps as the compute waves
 #pragma unroll
             for (int j = 0; j < SW_DEPTH; j++) {
                 const int t = tau + j;
@@ -379,9 +394,14 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                         }
                     }
                     uint32_t* w = imp + ((t + 2) & (SW_RING - 1)) * REC;
+                    // a pixel outside the stream (the one before its first, the one after its last): the record of a path
+                    // start (L = 0, delta = P2), which is what the rows inside a band find there (see the compute loop)
+                    const bool inside = t + 2 >= 0 && t + 2 < total_px;
+                    const unsigned long long p2q = ((unsigned long long)P2P2 << 32) | P2P2;
 #pragma unroll
                     for (int i = 0; i < NQ; i++)
-                        if (lane + 64 * i < RECQ) reinterpret_cast<unsigned long long*>(w)[lane + 64 * i] = ib[j][i];
+                        if (lane + 64 * i < RECQ)
+                            reinterpret_cast<unsigned long long*>(w)[lane + 64 * i] = inside ? ib[j][i] : (2 * (lane + 64 * i) >= 3 * PXW ? p2q : 0ull);
                     const int p = t + 2 + SW_DEPTH;   // <= t + 6: covered by the counter value waited for (t + 23 at t % 16 == 0)
                     const unsigned long long* g = ho_in + (size_t)((p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
 #pragma unroll
