@@ -492,7 +492,7 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     int rc;
     if ((rc = ensure(c, c->sw_handoff, (size_t)n_groups * (n_bands > 1 ? n_bands - 1 : 1) * (size_t)(ho_px + 1) * REC * 4))) return rc;
     if ((rc = ensure(c, c->sw_progress, (size_t)n_groups * n_bands * 4))) return rc;
-    if ((rc = ensure(c, c->sw_sink, (size_t)grid * NTHR * N * 4))) return rc;
+    if ((rc = ensure(c, c->sw_sink, (size_t)grid * NTHR * svk::sweep_sink_words<N>() * 4))) return rc;
     bool& attr_set = c->attr_sweep[second][N - 1][CW == 15];  // [2][8][2]  // per context: the attribute is per device
     if (!attr_set) {
         const void* fn = second ? reinterpret_cast<const void*>(&svk::k_sweep<N, true, CW>) : reinterpret_cast<const void*>(&svk::k_sweep<N, false, CW>);

@@ -56,7 +56,7 @@ struct SweepArgs {
     unsigned long long* handoff;   // [n_groups][n_bands - 1][ho_px + 1][REC / 2]: band-boundary records (+1 dummy)
     unsigned int* progress;        // [n_groups][n_bands]: stream pixels exported so far (zeroed before the launch)
     unsigned int* error;           // host-visible: set when a bounded wait ran out
-    uint32_t* sink;                // [gridDim.x * blockDim.x * N] u32: target of the stores of inactive steps
+    uint32_t* sink;                // [gridDim.x * blockDim.x * sweep_sink_words<N>()] u32: target of the stores of inactive steps
     int W1, H, W;
     int col0, min_disp;            // first computable column; minDisparity (EXT): stored disparity = (index + min_disp) * 16 + sub-pixel
     uint32_t P1P1, P2P2;
@@ -67,6 +67,8 @@ struct SweepArgs {
     unsigned long long* prof;      // diagnostic builds (-DSV_SWEEP_PROF): [gridDim.x][waves][4] cycle sums, else unused
 };
 
+template <int N>
+__host__ __device__ constexpr int sweep_sink_words() { return N < 2 ? 2 : N; }   // per thread: N words of S, or one 8-byte WTA record
 template <int N>
 __host__ __device__ constexpr int sweep_rec_words() { return 3 * 16 * N + 16; }
 // CW = compute waves per workgroup (4 image rows each) + one service wave
@@ -131,6 +133,9 @@ __device__ __forceinline__ void sweep_lane_min4(uint32_t& a, uint32_t& b, uint32
 #define SW_PROF(...)
 #endif
 
+#ifndef SW_ABL
+#define SW_ABL 0   // diagnostic builds: bit 0 no service-wave WTA, bit 1 sweep 1 stores S to the sink, bit 2 one path skipped (wrong results)
+#endif
 #ifndef SW_EARLY_FENCE
 #define SW_EARLY_FENCE __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -169,7 +174,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     uint2* const recg = a.rec + (size_t)f0 * H * a.W;
     const uint32_t rowoff = (uint32_t)yp * W1 * PXW + q * N;
     const uint32_t P1P1 = a.P1P1, P2P2 = a.P2P2;
-    uint32_t* const sinkp = a.sink + ((size_t)blockIdx.x * NTHR + tid) * N;
+    uint32_t* const sinkp = a.sink + ((size_t)blockIdx.x * NTHR + tid) * sweep_sink_words<N>();
 
     static_assert(sweep_lds_bytes<N, CW, SECOND>() <= 160 * 1024, "LDS of a CU");
     // sweep 2: winner-take-all slots [2][SW_ROWS][WSTR] (sweep_wta_words): written by a row's lanes, read by lane `row` of the service wave
@@ -221,7 +226,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
         act = (uint32_t)(step - ulane) < total_eff;
         off = act ? loff : row0off;
         load_regs<N>(Cg + off, c);
-        if (SECOND) load_regs<N>(Sg + off, s);
+        if (SECOND) load_regs<N>(((SW_ABL & 16) ? const_cast<uint32_t*>(Cg) : Sg) + off, s);
         lx++;
         const bool wrap = lx == W1;
         lx = wrap ? 0 : lx;
@@ -236,6 +241,13 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     unsigned int* const flag_out = a.progress + (size_t)group * a.n_bands + band;
     constexpr int NQ = (RECQ + 63) / 64;  // 8-byte words of a record per lane of the service wave (2 up to D = 128, 4 at 256)
     unsigned long long ib[SW_DEPTH][NQ];
+    int li[NQ];                     // this lane's 8-byte words of a record (past the end: the last word again)
+    unsigned long long startq[NQ];  // ... and what they hold in the record of a path start (L = 0, delta = P2)
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        li[i] = min(lane + 64 * i, RECQ - 1);
+        startq[i] = 2 * li[i] >= 3 * PXW ? (((unsigned long long)P2P2 << 32) | P2P2) : 0ull;
+    }
 #pragma unroll
     for (int j = 0; j < SW_DEPTH; j++)
 #pragma unroll
@@ -261,6 +273,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
             // carries (a store between the loads), so that the compiler's wait counts stay exact
             if (!SECOND && j > 0) store_regs<N>(sinkp, r0);
             issue(cb[j], sb[j], offq[j], actq[j], -SW_LEAD + j);
+            __builtin_amdgcn_sched_barrier(0);   // the loads stay in the order the loop issues them in (exact vmcnt counts)
         }
         SW_PROF(unsigned long long pacc[4] = {0, 0, 0, 0};)
         for (int tau = -SW_LEAD; tau < tau_end; tau += SW_DEPTH) {
@@ -293,17 +306,37 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                 uint32_t* dst = (r == SW_ROWS - 1) ? expo + (u & (SW_RING - 1)) * REC
                                                    : slot + ((j & 1) * (SW_ROWS + 1) + r + 1) * REC;
                 uint32_t* const ws = wrow + ((j + 1) & 1) * (SW_ROWS * WSTR);
+                if (SW_ABL & 12) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) L1[k] = cb[j][k];
+                    n1 = dr_dd[j & 1] ^ dr[j & 1][0];
+                } else
                 sweep_path<N>(cb[j], dr[j & 1], dr_dd[j & 1], P1P1, L1, n1, big0, big15);   // from (x-1, y-1): read two steps ago
                 store_regs<N>(dst + 2 * PXW + q * N, L1);
                 if (SECOND) store_regs<N>(ws + q * N, sp);
                 SW_EARLY_FENCE
+                if (SW_ABL & 8) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) L2[k] = cb[j][k] ^ dn[k];
+                    n2 = dn_dd;
+                } else
                 sweep_path<N>(cb[j], dn, dn_dd, P1P1, L2, n2, big0, big15);               // from (x,   y-1): read last step
                 store_regs<N>(dst + PXW + q * N, L2);
                 if (SECOND) ws[PXW + q] = wta_lane_key<N>(sp, q);
                 SW_EARLY_FENCE
+                if (SW_ABL & 8) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) L3[k] = cb[j][k] ^ in_dl[k];
+                    n3 = dd_dl;
+                } else
                 sweep_path<N>(cb[j], in_dl, dd_dl, P1P1, L3, n3, big0, big15);            // from (x+1, y-1): read now
                 store_regs<N>(dst + q * N, L3);
                 SW_EARLY_FENCE
+                if (SW_ABL & 8) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) L0[k] = cb[j][k] ^ r0[k];
+                    n0 = dd0;
+                } else
                 sweep_path<N>(cb[j], r0, dd0, P1P1, L0, n0, big0, big15);                  // horizontal: stays in registers
                 sweep_lane_min4(n0, n1, n2, n3);
                 // min over d of every path: the horizontal one into every lane (this row's next step), the
@@ -353,7 +386,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
                     // Unconditional (an inactive step writes to the thread's own sink slot): behind a branch the compiler
                     // cannot count this store, assumes it away and makes the next step's wait for its C load
                     // (s_waitcnt vmcnt) cover this store as well - a write round trip exposed in every step.
-                    store_regs<N>(active ? Sg + offq[j] : sinkp, snew);
+                    store_regs<N>((active && !(SW_ABL & 2)) ? Sg + offq[j] : sinkp, snew);
                 }
                 issue(cb[j], sb[j], offq[j], actq[j], tau + j + SW_DEPTH);
                 SW_STAMP(T3)
@@ -375,60 +408,59 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
             for (int j = 0; j < SW_DEPTH; j++) {
                 const int t = tau + j;
                 SW_STAMP(T0)
+                // Every vector memory operation of a step is issued by every service wave, in the same order, whatever its
+                // band and whatever the pixel (a band without a neighbour and a pixel outside the stream use the dummy record
+                // behind the last one; lanes past the end of a record repeat its last word): with loads or stores behind a
+                // condition the compiler cannot count what is in flight and waits for ALL of it - the previous step's stores
+                // included, a write round trip in every step - before it touches the record imported SW_DEPTH steps ago.
                 // import: pixel t + 2 of the previous band's last row (loaded SW_DEPTH steps ago) -> ring;
                 // row 0 reads pixel t' - 1 at step t'.
-                if (do_import) {
-                    if ((t & 15) == 0 && t + 23 > 0) {
-                        const unsigned need = (unsigned)min(t + 23, total_px);
-                        unsigned long long waited = 0, last = __builtin_amdgcn_s_memrealtime();
-                        while (__hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                            __builtin_amdgcn_s_sleep(16);
-                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                            waited += min(now - last, SW_WAIT_TICK_CAP);
-                            last = now;
-                            if (waited > SW_WAIT_TICKS) {
-                                (*abortp) = 1;
-                                if (lane == 0) __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                break;
-                            }
+                if (do_import && (t & 15) == 0 && t + 23 > 0) {
+                    const unsigned need = (unsigned)min(t + 23, total_px);
+                    unsigned long long waited = 0, last = __builtin_amdgcn_s_memrealtime();
+                    while (__hip_atomic_load(flag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                        __builtin_amdgcn_s_sleep(16);
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        waited += min(now - last, SW_WAIT_TICK_CAP);
+                        last = now;
+                        if (waited > SW_WAIT_TICKS) {
+                            (*abortp) = 1;
+                            if (lane == 0) __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
                         }
                     }
-                    uint32_t* w = imp + ((t + 2) & (SW_RING - 1)) * REC;
-                    // a pixel outside the stream (the one before its first, the one after its last): the record of a path
-                    // start (L = 0, delta = P2), which is what the rows inside a band find there (see the compute loop)
-                    const bool inside = t + 2 >= 0 && t + 2 < total_px;
-                    const unsigned long long p2q = ((unsigned long long)P2P2 << 32) | P2P2;
+                }
+                {
+                    unsigned long long* const w = reinterpret_cast<unsigned long long*>(imp + ((t + 2) & (SW_RING - 1)) * REC);
+                    // a pixel outside the stream (the one before its first, the one after its last) and every pixel of band 0:
+                    // the record of a path start (L = 0, delta = P2), which is what the rows inside a band find there
+                    const bool inside = do_import && t + 2 >= 0 && t + 2 < total_px;
 #pragma unroll
-                    for (int i = 0; i < NQ; i++)
-                        if (lane + 64 * i < RECQ)
-                            reinterpret_cast<unsigned long long*>(w)[lane + 64 * i] = inside ? ib[j][i] : (2 * (lane + 64 * i) >= 3 * PXW ? p2q : 0ull);
+                    for (int i = 0; i < NQ; i++) w[li[i]] = inside ? ib[j][i] : startq[i];
                     const int p = t + 2 + SW_DEPTH;   // <= t + 6: covered by the counter value waited for (t + 23 at t % 16 == 0)
                     const unsigned long long* g = ho_in + (size_t)((p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
 #pragma unroll
-                    for (int i = 0; i < NQ; i++)
-                        if (lane + 64 * i < RECQ) ib[j][i] = __hip_atomic_load(g + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i = 0; i < NQ; i++) ib[j][i] = __hip_atomic_load(g + li[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 // export: the record row SW_ROWS-1 wrote in the previous step (pixel t - 1 - 2*SW_ROWS)
-                if (do_export) {
+                {
                     const int p = t - 1 - 2 * SW_ROWS;
-                    const uint32_t* e = expo + (p & (SW_RING - 1)) * REC;
-                    unsigned long long* g = ho_out + (size_t)((p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
+                    const unsigned long long* e = reinterpret_cast<const unsigned long long*>(expo + (p & (SW_RING - 1)) * REC);
+                    unsigned long long* g = ho_out + (size_t)((do_export && p >= 0 && p < total_px) ? p : a.ho_px) * RECQ;
 #pragma unroll
-                    for (int i = 0; i < NQ; i++)
-                        if (lane + 64 * i < RECQ)
-                            __hip_atomic_store(g + lane + 64 * i, reinterpret_cast<const unsigned long long*>(e)[lane + 64 * i], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                    if ((t & 15) == 8) {
+                    for (int i = 0; i < NQ; i++) __hip_atomic_store(g + li[i], e[li[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (do_export && (t & 15) == 8) {
                         // every memory operation of this wave done (stores written through), then the counter
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         const int done = min(max(p + 1, 0), total_px);
                         if (lane == 0) __hip_atomic_store(flag_out, (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                if (SECOND) {
+                if (SECOND && !(SW_ABL & 1)) {
                     // slot of parity t & 1: written by the row during step t - 1 (S of step t - 2); the row writes the other one now
                     const uint2 rcd = wta_from_slot<N>(wrow + (j & 1) * (SW_ROWS * WSTR), uqk, a.min_disp);
-                    if (wrowok && wx >= 0 && wfi < nfr) recg[wrec + (uint32_t)(W1 - 1 - wx)] = rcd;
+                    const bool valid = wrowok && wx >= 0 && wfi < nfr;
+                    *(valid ? recg + (wrec + (uint32_t)(W1 - 1 - wx)) : reinterpret_cast<uint2*>(sinkp)) = rcd;
                     wx++;
                     const bool wrap = wx == W1;
                     wx = wrap ? 0 : wx;
