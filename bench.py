@@ -18,7 +18,7 @@ on the stream the kernels run on, after EVERY aggregation launch, over the K tim
 algorithmic bytes of a fused launch are what one pass must move: sweep 1 = 2 V per frame
 (C read, S written), sweep 2 = 2 V + 8 W H (C and S read, 8-byte WTA records written), cost = V + 2 W H,
 V = (W-D)*H*D*2; a per-path launch = 3 V.  traffic = HBM bytes of the same kernel from the
-committed rocprofv3 --pmc passes (profiles/r02_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, the gfx950
+committed rocprofv3 --pmc passes (profiles/r03_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, the gfx950
 correction of MI355X_MICROARCH.md), null when that file was taken from other kernel sources than the ones
 this run loads.  SURVEY 8(d)'s per-path model (3 V per path whatever the fusion) is reported beside it as
 per_path_model_gbs: a fused sweep moves a third of those bytes, so that figure exceeds the HBM peak and is
@@ -121,11 +121,11 @@ def source_sha():
 
 
 def pmc_traffic(config, batch):
-    """{kernel name: HBM bytes per launch} from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
+    """{kernel name: HBM bytes per launch} from the committed rocprofv3 PMC passes (profiles/r03_traffic.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this workload, gfx950 FETCH_SIZE x2 correction applied), the
     file's name and the sources it belongs to; ({}, ...) when no pass exists for this config / batch or the pass
     was taken from other kernel sources than the ones in the tree now."""
-    path = os.path.join("profiles", "r02_traffic.json")
+    path = os.path.join("profiles", "r03_traffic.json")
     try:
         with open(os.path.join(ROOT, path)) as f:
             t = json.load(f)
@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="stereo pairs per step per GPU (C2: 1024 pairs = 140 GB of the 288 GB of HBM; every workgroup pipeline then streams 32 frames and the fill/drain of the band pipeline is 5 %% of a launch instead of 10 %% at 512)")
+    ap.add_argument("--batch", type=int, default=1536, help="stereo pairs per step per GPU (C2: 1536 pairs = 213 GB of the 288 GB of HBM; every workgroup pipeline then streams 48 frames and the fill/drain of the band pipeline is 3.4 %% of a launch: 5 %% at 1024, 10 %% at 512)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -196,15 +196,16 @@ def main():
     lefts = [p[0] for p in pairs]
     rights = [p[1] for p in pairs]
     m = svhip.Matcher(W, H, params, device=dev)
-    while True:   # the volumes of the default batch take 140 of the 288 GB: on a card with less to give, halve it
+    while True:   # the volumes of the default batch take 213 of the 288 GB: on a card with less to give, step down
         try:
             m.set_batch(B)
             break
         except svhip.SvError as e:
             if B <= 64:
                 raise
-            sys.stderr.write("bench: batch %d does not fit (%s); trying %d\n" % (B, str(e)[:120], B // 2))
-            B //= 2
+            nxt = 1024 if B > 1024 else B // 2
+            sys.stderr.write("bench: batch %d does not fit (%s); trying %d\n" % (B, str(e)[:120], nxt))
+            B = nxt
     n_distinct = min(n_distinct, B)
     lt = torch.from_numpy(np.stack([lefts[i % n_distinct] for i in range(B)])).cuda()
     rt = torch.from_numpy(np.stack([rights[i % n_distinct] for i in range(B)])).cuda()

@@ -8,7 +8,9 @@ W, H, D = 640, 480, 128
 pairs = [synth.stereo_pair(202 + i, W, H, D) for i in range(4)]
 m = svhip.Matcher(W, H, svhip.default_params(D, 8))
 m.set_stream(torch.cuda.current_stream().cuda_stream)
-for nb in (1, 4, 8, 16, 24, 32, 48, 64, 96, 128, 256, 512, 1024, 1536):
+batches = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 256, 512, 1024, 1536]
+print('lib', os.environ.get('SVHIP_LIB', 'default'), 'SV_FAN_CHUNK', os.environ.get('SV_FAN_CHUNK'))
+for nb in batches:
     m.set_batch(nb)
     lt = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(nb)])).cuda()
     rt = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(nb)])).cuda()

@@ -105,6 +105,7 @@ struct sv_ctx {
     // concurrent paths for small batches (run_paths_fanout)
     Buf Lbuf[8];
     int fanout_mode = 0;               // 0 auto, 1 always, -1 never
+    int fan_chunk = 0;                 // frames per all-paths launch (SV_FAN_CHUNK); 0: from the geometry
     int last_agg_launches = 0, last_agg_sweeps = 0;  // of the most recent compute call (sv_last_aggregation)
     int last_sweep_cw = 0;             // compute waves per workgroup of the most recent sweep launch (sv_last_sweep_waves)
     int fuse_wta_min_batch = 6;  // batches below this run WTA as its own kernel (see run_sgm; crossover measured at 640x480 D=128)
@@ -335,27 +336,31 @@ void launch_agg_to(sv_ctx* c, int dir, int mode, int nb, uint32_t* Sout, hipStre
 }
 void launch_agg(sv_ctx* c, int dir, int mode, int nb) { launch_agg_to(c, dir, mode, nb, (uint32_t*)c->S.p, c->stream); }
 
+// frames f0 .. f0 + nb - 1 of the batch (the L volumes hold one chunk and are reused by the next)
 template <int N>
-void launch_paths_sum_n(sv_ctx* c, const svk::PathSet& ps, const svk::PathBufs& pb, int nb) {
+void launch_paths_sum_n(sv_ctx* c, const svk::PathSet& ps, const svk::PathBufs& pb, int f0, int nb) {
     const int W1 = geo_w1(c->W, c->prm), H = c->H;
     constexpr int U = N <= 4 ? 4 : 2;
     const int nch = W1 > H ? W1 : H;
-    hipLaunchKernelGGL((svk::k_agg_paths<N, U>), dim3((nch + 3) / 4, nb, pb.n), dim3(64), 0, c->stream, (const uint32_t*)c->C.p, ps,
-                       W1, H, (uint32_t)c->prm.P1 * 0x10001u, (uint32_t)c->prm.P2 * 0x10001u);
     const size_t npx = (size_t)W1 * H;
+    const uint32_t* Cf = (const uint32_t*)c->C.p + (size_t)f0 * npx * (16 * N);
+    uint2* recf = (uint2*)c->rec.p + (size_t)f0 * c->H * c->W;
+    hipLaunchKernelGGL((svk::k_agg_paths<N, U>), dim3((nch + 3) / 4, nb, pb.n), dim3(64), 0, c->stream, Cf, ps,
+                       W1, H, (uint32_t)c->prm.P1 * 0x10001u, (uint32_t)c->prm.P2 * 0x10001u);
     hipLaunchKernelGGL((svk::k_sum_wta<N>), dim3((unsigned)((npx * 16 + 255) / 256), nb), dim3(256), 0, c->stream, pb,
-                       (uint2*)c->rec.p, c->W, c->H, c->prm.uniqueness_ratio, geo_col0(c->W, c->prm), W1, c->prm.min_disparity);
+                       recf, c->W, c->H, c->prm.uniqueness_ratio, geo_col0(c->W, c->prm), W1, c->prm.min_disparity);
 }
 
 // Small batches are latency-bound (one path launch of one 640x480 frame is 128 waves on 1024
 // SIMDs), so all paths run side by side in one launch, each writing its own L volume, then one
 // streaming kernel sums them and runs WTA.  More bytes (3V per path instead of ~2.75V) but the
 // eight recurrences overlap.
-int run_paths_fanout(sv_ctx* c, int nb) {
+int run_paths_fanout(sv_ctx* c, int nb, int chunk) {
     static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const sv_params& p = c->prm;
-    const size_t vol = (size_t)geo_w1(c->W, p) * c->H * p.num_disparities * 2 * nb;
+    if (chunk < 1 || chunk > nb) chunk = nb;
+    const size_t vol = (size_t)geo_w1(c->W, p) * c->H * p.num_disparities * 2 * chunk;
     svk::PathSet ps;
     svk::PathBufs pb;
     pb.n = 0;
@@ -370,16 +375,19 @@ int run_paths_fanout(sv_ctx* c, int nb) {
             pb.L[i] = (const uint32_t*)c->Lbuf[i].p;
         }
     for (int i = pb.n; i < 8; i++) { ps.L[i] = ps.L[0]; ps.dx[i] = ps.dx[0]; ps.dy[i] = ps.dy[0]; pb.L[i] = pb.L[0]; }
-    c->last_agg_launches += 1;
-    switch (p.num_disparities / 32) {
-        case 1: launch_paths_sum_n<1>(c, ps, pb, nb); break;
-        case 2: launch_paths_sum_n<2>(c, ps, pb, nb); break;
-        case 3: launch_paths_sum_n<3>(c, ps, pb, nb); break;
-        case 4: launch_paths_sum_n<4>(c, ps, pb, nb); break;
-        case 5: launch_paths_sum_n<5>(c, ps, pb, nb); break;
-        case 6: launch_paths_sum_n<6>(c, ps, pb, nb); break;
-        case 7: launch_paths_sum_n<7>(c, ps, pb, nb); break;
-        default: launch_paths_sum_n<8>(c, ps, pb, nb); break;
+    for (int f0 = 0; f0 < nb; f0 += chunk) {
+        const int n = nb - f0 < chunk ? nb - f0 : chunk;
+        c->last_agg_launches += 1;
+        switch (p.num_disparities / 32) {
+            case 1: launch_paths_sum_n<1>(c, ps, pb, f0, n); break;
+            case 2: launch_paths_sum_n<2>(c, ps, pb, f0, n); break;
+            case 3: launch_paths_sum_n<3>(c, ps, pb, f0, n); break;
+            case 4: launch_paths_sum_n<4>(c, ps, pb, f0, n); break;
+            case 5: launch_paths_sum_n<5>(c, ps, pb, f0, n); break;
+            case 6: launch_paths_sum_n<6>(c, ps, pb, f0, n); break;
+            case 7: launch_paths_sum_n<7>(c, ps, pb, f0, n); break;
+            default: launch_paths_sum_n<8>(c, ps, pb, f0, n); break;
+        }
     }
     return SV_OK;
 }
@@ -779,11 +787,15 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         }
         // few frames: all remaining paths at once, each into its own volume, then sum + WTA
         const int n_rest = __builtin_popcount(rest);
-        const long waves_per_launch = (long)nb * ((W1 > H ? W1 : H) + 3) / 4;
-        const bool fan = !c->debug && !c->force_fuse && first && n_rest >= 2 && c->fanout_mode >= 0 &&
-                         (c->fanout_mode > 0 || waves_per_launch <= 4L * c->n_cu);
+        // Below the sweeps' batch: every path of a chunk of frames in one launch, chunk after chunk.  A chunk holds as many
+        // frames as give a path about two waves per CU (4 frames at 640x480 on 256 CUs: 3500 frames/s, against 3100-3250
+        // for one launch per path over 8-17 frames; scratch/perf_batches.py), SV_FAN_CHUNK overrides.
+        const long waves_per_frame = ((W1 > H ? W1 : H) + 3) / 4;
+        int fan_chunk = c->fan_chunk > 0 ? c->fan_chunk : (int)((2L * c->n_cu + waves_per_frame / 2) / waves_per_frame);
+        if (fan_chunk < 1) fan_chunk = 1;
+        const bool fan = !c->debug && !c->force_fuse && first && n_rest >= 2 && c->fanout_mode >= 0;
         if (fan) {
-            int rc = run_paths_fanout(c, nb);
+            int rc = run_paths_fanout(c, nb, fan_chunk);
             if (rc) return rc;
             rest = 0;
             wta_done = true;
@@ -910,6 +922,7 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     if (const char* e = getenv("SV_FUSE_WTA_MIN_BATCH")) c->fuse_wta_min_batch = atoi(e);  // tuning knobs
     if (const char* e = getenv("SV_SWEEP_MIN_BATCH")) c->sweep_min_batch = atoi(e);
     if (const char* e = getenv("SV_SWEEP_MODE")) c->sweep_mode = atoi(e);
+    if (const char* e = getenv("SV_FAN_CHUNK")) c->fan_chunk = atoi(e);
     if (const char* e = getenv("SV_SWEEP_CW")) c->sweep_cw = atoi(e) == 7 ? 7 : (atoi(e) == 15 ? 15 : 0);
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("SV_SWEEP_NCU")) c->n_cu = atoi(e) > 0 ? atoi(e) : c->n_cu;  // tests: few groups, many frames each
