@@ -314,7 +314,7 @@ def main():
         fps = frames / elapsed
         V = (W - D) * H * D * 2
         n_paths = bin(params.path_mask).count("1")
-        fused = n_sweeps == n_launch and n_sweeps > 0
+        fused = n_sweeps > 0   # (a few frames beyond whole pipeline rounds may have gone through the all-paths kernels: more launches than sweeps)
         cw = m.last_sweep_waves()
         # per-launch algorithmic bytes and kernel names, in launch order
         if fused:

@@ -355,7 +355,7 @@ void launch_paths_sum_n(sv_ctx* c, const svk::PathSet& ps, const svk::PathBufs& 
 // SIMDs), so all paths run side by side in one launch, each writing its own L volume, then one
 // streaming kernel sums them and runs WTA.  More bytes (3V per path instead of ~2.75V) but the
 // eight recurrences overlap.
-int run_paths_fanout(sv_ctx* c, int nb, int chunk) {
+int run_paths_fanout(sv_ctx* c, int f_start, int nb, int chunk) {
     static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int DY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const sv_params& p = c->prm;
@@ -375,8 +375,8 @@ int run_paths_fanout(sv_ctx* c, int nb, int chunk) {
             pb.L[i] = (const uint32_t*)c->Lbuf[i].p;
         }
     for (int i = pb.n; i < 8; i++) { ps.L[i] = ps.L[0]; ps.dx[i] = ps.dx[0]; ps.dy[i] = ps.dy[0]; pb.L[i] = pb.L[0]; }
-    for (int f0 = 0; f0 < nb; f0 += chunk) {
-        const int n = nb - f0 < chunk ? nb - f0 : chunk;
+    for (int f0 = f_start; f0 < f_start + nb; f0 += chunk) {
+        const int n = f_start + nb - f0 < chunk ? f_start + nb - f0 : chunk;
         c->last_agg_launches += 1;
         switch (p.num_disparities / 32) {
             case 1: launch_paths_sum_n<1>(c, ps, pb, f0, n); break;
@@ -564,15 +564,35 @@ int sweep_pipes(const sv_ctx* c, int cw) {
 // of W1 steps through every pipeline after (bands - 1) * (2 * rows + 2) steps of fill.  Measured at
 // 640x480 D=128 (scratch/perf_cw.py), in units of a 16-wave streaming step: 16-wave workgroups 1.0 per
 // streaming step and 1.44 per fill step, 8-wave workgroups (two per CU) 1.063 and 0.83.
+// predicted length of one sweep launch over n frames with cw compute waves per workgroup, in 16-wave streaming steps
+double sweep_cost(const sv_ctx* c, int cw, int n) {
+    const int W1 = geo_w1(c->W, c->prm);
+    const int rows = 4 * cw, bands = (c->H + rows - 1) / rows, pipes = sweep_pipes(c, cw);
+    const double stream = cw == 15 ? 1.0 : 1.063, fill = cw == 15 ? 1.44 : 0.83;
+    return (double)((n + pipes - 1) / pipes) * W1 * stream + (double)(bands - 1) * (2 * rows + 2) * fill;
+}
 int sweep_cw_for(const sv_ctx* c, int nb) {
     if (c->prm.num_disparities > 128) return 7;
     if (c->sweep_cw) return c->sweep_cw;
+    return sweep_cost(c, 7, nb) < sweep_cost(c, 15, nb) ? 7 : 15;
+}
+// How many of nb frames go through the sweeps when the rest may take the all-paths kernels (run_paths_fanout): a launch
+// streams whole rounds of one frame per pipeline, so a few frames beyond a full round cost a whole round more (32 frames
+// on 28 pipelines: 6.5 ms against 4.8 ms for 28) - unless they go the other way.  One frame through the all-paths
+// kernels costs about 3.1e-4 streaming steps per pixel (640x480, D=128: 0.26 ms = 76 steps of the two sweeps).
+int sweep_share(const sv_ctx* c, int nb) {
     const int W1 = geo_w1(c->W, c->prm);
-    auto cost = [&](int cw, double stream, double fill) {
-        const int rows = 4 * cw, bands = (c->H + rows - 1) / rows, pipes = sweep_pipes(c, cw);
-        return (double)((nb + pipes - 1) / pipes) * W1 * stream + (double)(bands - 1) * (2 * rows + 2) * fill;
-    };
-    return cost(7, 1.063, 0.83) < cost(15, 1.0, 1.44) ? 7 : 15;
+    const double fan_unit = 3.1e-4 * W1 * c->H;
+    int best_n = nb;
+    double best = sweep_cost(c, sweep_cw_for(c, nb), nb);
+    for (int cw = 7; cw <= 15; cw += 8) {
+        if ((c->prm.num_disparities > 128 && cw == 15) || (c->sweep_cw && cw != c->sweep_cw)) continue;
+        const int pipes = sweep_pipes(c, cw), n = nb / pipes * pipes;
+        if (n <= 0 || n == nb) continue;
+        const double cost = sweep_cost(c, cw, n) + (nb - n) * fan_unit;
+        if (cost < best) { best = cost; best_n = n; }
+    }
+    return best_n;
 }
 int launch_sweep(sv_ctx* c, bool second, int nb) {
     c->last_sweep_cw = sweep_cw_for(c, nb);
@@ -769,8 +789,17 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         const bool sw2 = sw1 && (p.path_mask & 0xF0u) == 0xF0u;
         uint32_t rest = p.path_mask;
         bool first = true;
+        // Below the sweeps' batch: every path of a chunk of frames in one launch, chunk after chunk.  A chunk holds as many
+        // frames as give a path about two waves per CU (4 frames at 640x480 on 256 CUs: 3500 frames/s, against 3100-3250
+        // for one launch per path over 8-17 frames; scratch/perf_batches.py), SV_FAN_CHUNK overrides.
+        const long waves_per_frame = ((W1 > H ? W1 : H) + 3) / 4;
+        int fan_chunk = c->fan_chunk > 0 ? c->fan_chunk : (int)((2L * c->n_cu + waves_per_frame / 2) / waves_per_frame);
+        if (fan_chunk < 1) fan_chunk = 1;
+        const bool fan_ok = !c->debug && !c->force_fuse && c->fanout_mode >= 0 && __builtin_popcount(p.path_mask) >= 2;
+        // frames 0 .. n_sw - 1 through the sweeps, the rest (a few frames beyond whole rounds of the pipelines) the other way
+        const int n_sw = (sw2 && fan_ok && c->sweep_mode == 0 && c->sweep_min_batch == 0) ? sweep_share(c, nb) : nb;
         if (sw1) {
-            int rc = launch_sweep(c, false, nb);
+            int rc = launch_sweep(c, false, n_sw);
             if (rc) return rc;
             rest &= ~0x0Fu;
             first = false;
@@ -778,24 +807,22 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
             agg_mark();
         }
         if (sw2) {
-            int rc = launch_sweep(c, true, nb);
+            int rc = launch_sweep(c, true, n_sw);
             if (rc) return rc;
             rest = 0;
             wta_done = true;
             c->last_agg_launches++; c->last_agg_sweeps++;
             agg_mark();
+            if (n_sw < nb) {
+                rc = run_paths_fanout(c, n_sw, nb - n_sw, fan_chunk);
+                if (rc) return rc;
+                agg_mark();
+            }
         }
-        // few frames: all remaining paths at once, each into its own volume, then sum + WTA
         const int n_rest = __builtin_popcount(rest);
-        // Below the sweeps' batch: every path of a chunk of frames in one launch, chunk after chunk.  A chunk holds as many
-        // frames as give a path about two waves per CU (4 frames at 640x480 on 256 CUs: 3500 frames/s, against 3100-3250
-        // for one launch per path over 8-17 frames; scratch/perf_batches.py), SV_FAN_CHUNK overrides.
-        const long waves_per_frame = ((W1 > H ? W1 : H) + 3) / 4;
-        int fan_chunk = c->fan_chunk > 0 ? c->fan_chunk : (int)((2L * c->n_cu + waves_per_frame / 2) / waves_per_frame);
-        if (fan_chunk < 1) fan_chunk = 1;
-        const bool fan = !c->debug && !c->force_fuse && first && n_rest >= 2 && c->fanout_mode >= 0;
+        const bool fan = fan_ok && first && n_rest >= 2;
         if (fan) {
-            int rc = run_paths_fanout(c, nb, fan_chunk);
+            int rc = run_paths_fanout(c, 0, nb, fan_chunk);
             if (rc) return rc;
             rest = 0;
             wta_done = true;
