@@ -171,13 +171,14 @@ def wta(S, W, uniq, minD=0):
 
 
 def lrcheck(disp, raw, mins, D, thresh, minD=0):
-    """A7 (with min_disparity as cv::StereoSGBM has it: disp2 holds true disparities, none = minD - 1)."""
+    """A7 (with min_disparity as cv::StereoSGBM has it: disp2 holds true disparities; an unwritten entry keeps the scaled
+    marker (minD - 1) * 16, which the test "disp2 >= minD" takes for a disparity once minD >= 2)."""
     H, W = disp.shape
     col0, colN = columns(W, D, minD)
     inv = (minD - 1) * 16
     out = disp.copy()
     for y in range(H):
-        d2 = np.full(W, minD - 1, np.int32)
+        d2 = np.full(W, (minD - 1) * 16, np.int32)
         c2 = np.full(W, 32767, np.int32)
         for x in range(colN - 1, col0 - 1, -1):
             d = int(raw[y, x])

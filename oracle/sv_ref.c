@@ -523,7 +523,11 @@ void svref_lrcheck(int16_t* disp, const int16_t* raw, const int16_t* mins, int W
                    int16_t* disp2_out) {
     svref_lrcheck_min(disp, raw, mins, W, H, D, 0, thresh, disp2_out);
 }
-/* with min_disparity (EXT): disp2 holds true disparities (index + minD), "none" = minD - 1 */
+/* with min_disparity (EXT): disp2 holds true disparities (index + minD).  An entry nobody wrote keeps the marker
+ * cv::StereoSGBM initialises it with, INVALID_DISP_SCALED = (minD - 1) * 16 - the SCALED marker in an unscaled
+ * array - and its test "disp2 >= minD" (the reference shows the pattern for minD = 0, aggregation.cu:703,732) lets
+ * that marker through as a disparity as soon as (minD - 1) * 16 >= minD, i.e. for every minD >= 2: an unwritten
+ * right-image column then counts as disparity (minD - 1) * 16 in the consistency test.  Reproduced as is. */
 void svref_lrcheck_min(int16_t* disp, const int16_t* raw, const int16_t* mins, int W, int H, int D, int minD, int thresh,
                        int16_t* disp2_out) {
     const int col0 = geo_col0(W, D, minD), colN = geo_colN(W, D, minD), inv = geo_invalid(minD);
@@ -533,7 +537,7 @@ void svref_lrcheck_min(int16_t* disp, const int16_t* raw, const int16_t* mins, i
         int16_t* dp = disp + (size_t)y * W;
         const int16_t* rw = raw + (size_t)y * W;
         const int16_t* mn = mins + (size_t)y * W;
-        for (int x = 0; x < W; x++) { d2c[x] = SHRT_MAX_I; disp2[x] = (int16_t)(minD - 1); }
+        for (int x = 0; x < W; x++) { d2c[x] = SHRT_MAX_I; disp2[x] = (int16_t)((minD - 1) * 16); }
         for (int x = colN - 1; x >= col0; x--) {
             int d = rw[x];
             if (d < 0) continue;

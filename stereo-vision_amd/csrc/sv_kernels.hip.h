@@ -944,6 +944,17 @@ __global__ __launch_bounds__(256) void k_sum_wta(PathBufs pb, uint2* __restrict_
 // col0 / colN: the computable columns; min_disp (EXT): the raw field of a record is the cost index, the pixel it
 // matches in the right image is x - index - min_disp, and "none" is (min_disp - 1) * 16.  The disparity the key
 // stands for, x_src - x2, is the true one (index + min_disp), which is what cv::StereoSGBM keeps in disp2.
+// One half of the consistency test: does disp2 at column xx disagree with dref by more than thresh?  k = the column's key
+// (all ones: nobody matched into it).  cv::StereoSGBM leaves its scaled marker (minD - 1) * 16 in such an entry and tests
+// "disp2 >= minD", which the marker passes for minD >= 2: the entry then counts as that disparity (oracle: svref_lrcheck_min).
+__device__ __forceinline__ bool lr_disagrees(uint32_t k, int xx, int dref, int min_disp, int thresh) {
+    int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - xx;
+    if (k == 0xFFFFFFFFu) {
+        d2 = (min_disp - 1) * 16;
+        if (d2 < min_disp) return false;
+    }
+    return abs(d2 - dref) > thresh;
+}
 __global__ __launch_bounds__(256) void k_lrcheck(const uint2* __restrict__ rec, int16_t* __restrict__ out, int W, int col0, int colN,
                                                   int min_disp, int thresh) {
     extern __shared__ uint32_t keys[];
@@ -966,11 +977,11 @@ __global__ __launch_bounds__(256) void k_lrcheck(const uint2* __restrict__ rec, 
             bool f1 = false, f2 = false;
             if (0 <= _x && _x < W) {
                 uint32_t k = keys[_x];
-                if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - _x; f1 = abs(d2 - _d) > thresh; }
+                f1 = lr_disagrees(k, _x, _d, min_disp, thresh);
             }
             if (0 <= x_ && x_ < W) {
                 uint32_t k = keys[x_];
-                if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - x_; f2 = abs(d2 - d_) > thresh; }
+                f2 = lr_disagrees(k, x_, d_, min_disp, thresh);
             }
             if (f1 && f2) d1 = inv;
         }
@@ -1015,11 +1026,11 @@ __global__ __launch_bounds__(256) void k_lr_median(const uint2* __restrict__ rec
                 bool f1 = false, f2 = false;
                 if (0 <= _x && _x < W) {
                     uint32_t k = keys[_x];
-                    if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - _x; f1 = abs(d2 - _d) > thresh; }
+                    f1 = lr_disagrees(k, _x, _d, min_disp, thresh);
                 }
                 if (0 <= x_ && x_ < W) {
                     uint32_t k = keys[x_];
-                    if (k != 0xFFFFFFFFu) { int d2 = (0xFFFF - (int)(k & 0xFFFFu)) - x_; f2 = abs(d2 - d_) > thresh; }
+                    f2 = lr_disagrees(k, x_, d_, min_disp, thresh);
                 }
                 if (f1 && f2) d1 = inv;
             }
