@@ -439,7 +439,9 @@ const char* sv_version(void);
  * flight, so uploads, kernels and downloads overlap per device.  No collective and no traffic between devices; every
  * pair has its own output pointer, so results are in submission order by construction.  The call returns when every
  * pair is done (or with the first error; sv_pool_last_error).  Buffers as for sv_submit_gray_batch_host (pinned
- * memory makes the copies asynchronous).  The reference handles one pair per updateModule() on one GPU
+ * memory makes the copies asynchronous).  One caller at a time per pool: the call is not reentrant (its contexts are
+ * single-threaded-per-context like every sv_ctx); different pools may run concurrently.  A context whose host thread
+ * cannot be started is served by the calling thread instead.  The reference handles one pair per updateModule() on one GPU
  * (DispModule.cpp:661-814, bova_sgm.cu:7-30); no counterpart there.                                           */
 typedef struct sv_pool sv_pool;
 int sv_pool_create(sv_pool** out, const int* devices, int n_devices, int width, int height, const sv_params* params, int batch);

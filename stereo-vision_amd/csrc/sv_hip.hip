@@ -43,21 +43,24 @@ int* g_scratch_dev[MAX_DEVICES] = {};   // per device: device address of its cop
 std::mutex g_scratch_mu;
 
 // called with `device` current
-hipError_t static_scratch_lookup(int device) {
+hipError_t static_scratch_lookup(int device, int** out) {
     if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (g_scratch_dev[device]) return hipSuccess;
-    int* ptr = nullptr;
-    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(sv_static_scratch));
-    if (e != hipSuccess) return e;
-    if (!ptr) return hipErrorInvalidSymbol;
-    g_scratch_dev[device] = ptr;
+    if (!g_scratch_dev[device]) {
+        int* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(sv_static_scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_dev[device] = ptr;
+    }
+    *out = g_scratch_dev[device];   // the context keeps its own copy: no entry point reads the table without the mutex
     return hipSuccess;
 }
 }  // namespace
 
 struct sv_ctx {
     int device = 0;
+    int* static_scratch = nullptr;     // this device's copy of sv_static_scratch (hipGetSymbolAddress in sv_create)
     int W = 0, H = 0;
     int batch = 1;  // frames per launch the volume buffers are sized for
     bool core_ok = false;  // the core buffers (statistics, C, S, records, planes) are allocated for `batch` frames
@@ -89,6 +92,8 @@ struct sv_ctx {
         Buf in_l, in_r, out;      // device: [n][H][W] u8 x 2, [n][H][W] i16
         hipEvent_t up = nullptr, computed = nullptr, done = nullptr;
         bool busy = false;
+        std::vector<int16_t*> dst;  // where the batch's frames go on the host (kept for the retry in sv_wait_batch_host)
+        size_t ds = 0;
     } bslot[SV_BATCH_SLOTS];
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     bool bslots_ok = false;
@@ -99,13 +104,15 @@ struct sv_ctx {
     unsigned int* sw_error = nullptr;  // pinned host word the sweep kernels set when a bounded wait runs out
     int sweep_mode = 0;                // 0 auto (batch >= sweep_min_batch), 1 always (when applicable), -1 never
     int sweep_min_batch = 0;           // > 0: fixed threshold (SV_SWEEP_MIN_BATCH); 0: one frame per workgroup pipeline
-    bool attr_sweep[2][8][2] = {}, attr_cost2[2][3][8] = {}, attr_lrcheck = false;
+    int occ_sweep[2][8][2] = {};       // workgroups of a sweep kernel instance a CU holds (0: not asked yet, -1: the query failed)
+    bool attr_cost2[2][3][8] = {}, attr_lrcheck = false;
     int sweep_cw = 0;                  // compute waves per sweep workgroup: 15 (one workgroup per CU), 7 (two), 0 = chosen per launch (SV_SWEEP_CW)
     int n_cu = 256;
     // concurrent paths for small batches (run_paths_fanout)
     Buf Lbuf[8];
     int fanout_mode = 0;               // 0 auto, 1 always, -1 never
     int fan_chunk = 0;                 // frames per all-paths launch (SV_FAN_CHUNK); 0: from the geometry
+    int sweep_fault = 0;               // fault injection for tests (SV_SWEEP_FAULT): sweep launches left that report a timeout
     int last_agg_launches = 0, last_agg_sweeps = 0;  // of the most recent compute call (sv_last_aggregation)
     int last_sweep_cw = 0;             // compute waves per workgroup of the most recent sweep launch (sv_last_sweep_waves)
     int fuse_wta_min_batch = 6;  // batches below this run WTA as its own kernel (see run_sgm; crossover measured at 640x480 D=128)
@@ -479,12 +486,26 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     const int D = c->prm.num_disparities, W1 = geo_w1(c->W, c->prm), H = c->H;
     const int n_bands = (H + ROWS - 1) / ROWS;
     const size_t lds = second ? svk::sweep_lds_bytes<N, CW, true>() : svk::sweep_lds_bytes<N, CW, false>();
+    const void* fn = second ? reinterpret_cast<const void*>(&svk::k_sweep<N, true, CW>) : reinterpret_cast<const void*>(&svk::k_sweep<N, false, CW>);
+    int& occ = c->occ_sweep[second][N - 1][CW == 15];  // [2][8][2], per context: workgroups of this kernel a CU holds (0: not asked yet)
+    if (occ == 0) {
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, NTHR, lds) != hipSuccess || q < 1) { (void)hipGetLastError(); q = -1; }
+        occ = q;
+    }
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2048 / NTHR) per_cu = 2048 / NTHR;
+    if (occ > 0 && occ < per_cu) per_cu = occ;   // what the runtime says fits (registers included), when it is less than LDS and threads allow
     if (per_cu < 1) per_cu = 1;
-    int n_groups = c->n_cu * per_cu / n_bands;
-    if (n_groups < 1) n_groups = 1;
-    if (n_groups > nb) n_groups = nb;
+    // Frame pipelines (groups of n_bands workgroups) the chip holds at once.  A launch never has more: band b waits for
+    // band b-1 of its group, and only a launch whose workgroups are all resident is independent of the order in which
+    // the dispatcher starts them.  More frames than that = more frames per group, and when a group's
+    // block of volumes would pass the kernel's 32-bit offsets, further launches.  (SV_SWEEP_NCU overrides the CU count
+    // for tests, which oversubscribe on purpose.)
+    int resident = c->n_cu * per_cu / n_bands;
+    if (resident < 1) resident = 1;
+    int n_groups = resident < nb ? resident : nb;
     int fpg = (nb + n_groups - 1) / n_groups;
     // a group's block of C / S must stay below 2^32 dwords (the kernel keeps 32-bit dword offsets from the
     // group's first frame and widens them when it forms the address)
@@ -492,44 +513,42 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     const int fpg_max = (int)(((size_t)1 << 34) / frame_bytes) - 1;
     if (fpg_max < 1) return fail(c, SV_ERR_UNSUPPORTED, "frame too large for the sweep kernel");
     if (fpg > fpg_max) fpg = fpg_max;
-    n_groups = (nb + fpg - 1) / fpg;  // contiguous blocks of fpg frames; the last block may be shorter
     if ((long)fpg * W1 > (1L << 30)) return fail(c, SV_ERR_UNSUPPORTED, "batch too large for the sweep kernel");
     const int ho_px = (fpg * W1 + 15) & ~15;
     constexpr int REC = svk::sweep_rec_words<N>();
-    const int grid = n_groups * n_bands;
+    const int frames_per_launch = resident * fpg;   // >= nb unless fpg was clamped
     int rc;
-    if ((rc = ensure(c, c->sw_handoff, (size_t)n_groups * (n_bands > 1 ? n_bands - 1 : 1) * (size_t)(ho_px + 1) * REC * 4))) return rc;
-    if ((rc = ensure(c, c->sw_progress, (size_t)n_groups * n_bands * 4))) return rc;
-    if ((rc = ensure(c, c->sw_sink, (size_t)grid * NTHR * svk::sweep_sink_words<N>() * 4))) return rc;
-    bool& attr_set = c->attr_sweep[second][N - 1][CW == 15];  // [2][8][2]  // per context: the attribute is per device
-    if (!attr_set) {
-        const void* fn = second ? reinterpret_cast<const void*>(&svk::k_sweep<N, true, CW>) : reinterpret_cast<const void*>(&svk::k_sweep<N, false, CW>);
-        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    HIPCHK(c, hipMemsetAsync(c->sw_progress.p, 0, (size_t)n_groups * n_bands * 4, c->stream));
-    svk::SweepArgs a;
-    a.C = (const uint32_t*)c->C.p;
-    a.S = (uint32_t*)c->S.p;
-    a.rec = (uint2*)c->rec.p;
-    a.handoff = (unsigned long long*)c->sw_handoff.p;
-    a.progress = (unsigned int*)c->sw_progress.p;
-    a.error = c->sw_error;
-    a.sink = (uint32_t*)c->sw_sink.p;
-    a.W1 = W1; a.H = H; a.W = c->W;
-    a.col0 = geo_col0(c->W, c->prm); a.min_disp = c->prm.min_disparity;
-    a.P1P1 = (uint32_t)c->prm.P1 * 0x10001u;
-    a.P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
-    a.uniq = c->prm.uniqueness_ratio;
-    a.n_frames = nb; a.n_groups = n_groups; a.n_bands = n_bands; a.ho_px = ho_px; a.fpg = fpg;
-    a.prof = nullptr;
+    for (int f0 = 0; f0 < nb; f0 += frames_per_launch) {
+        const int nf = nb - f0 < frames_per_launch ? nb - f0 : frames_per_launch;
+        n_groups = (nf + fpg - 1) / fpg;  // contiguous blocks of fpg frames; the last block may be shorter
+        const int grid = n_groups * n_bands;
+        if ((rc = ensure(c, c->sw_handoff, (size_t)n_groups * (n_bands > 1 ? n_bands - 1 : 1) * (size_t)(ho_px + 1) * REC * 4))) return rc;
+        if ((rc = ensure(c, c->sw_progress, (size_t)n_groups * n_bands * 4))) return rc;
+        if ((rc = ensure(c, c->sw_sink, (size_t)grid * NTHR * svk::sweep_sink_words<N>() * 4))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->sw_progress.p, 0, (size_t)n_groups * n_bands * 4, c->stream));
+        svk::SweepArgs a;
+        a.C = (const uint32_t*)c->C.p + (size_t)f0 * (frame_bytes / 4);
+        a.S = (uint32_t*)c->S.p + (size_t)f0 * (frame_bytes / 4);
+        a.rec = (uint2*)c->rec.p + (size_t)f0 * H * c->W;
+        a.handoff = (unsigned long long*)c->sw_handoff.p;
+        a.progress = (unsigned int*)c->sw_progress.p;
+        a.error = c->sw_error;
+        a.sink = (uint32_t*)c->sw_sink.p;
+        a.W1 = W1; a.H = H; a.W = c->W;
+        a.col0 = geo_col0(c->W, c->prm); a.min_disp = c->prm.min_disparity;
+        a.P1P1 = (uint32_t)c->prm.P1 * 0x10001u;
+        a.P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
+        a.uniq = c->prm.uniqueness_ratio;
+        a.n_frames = nf; a.n_groups = n_groups; a.n_bands = n_bands; a.ho_px = ho_px; a.fpg = fpg;
+        a.prof = nullptr;
 #ifdef SV_SWEEP_PROF
-    if ((rc = ensure(c, c->sw_prof, (size_t)grid * (CW + 1) * 4 * 8 * 2))) return rc;
-    a.prof = (unsigned long long*)c->sw_prof.p + (second ? (size_t)grid * (CW + 1) * 4 : 0);
-    c->sw_prof_n = grid * (CW + 1) * 4 * 2;
+        if ((rc = ensure(c, c->sw_prof, (size_t)grid * (CW + 1) * 4 * 8 * 2))) return rc;
+        a.prof = (unsigned long long*)c->sw_prof.p + (second ? (size_t)grid * (CW + 1) * 4 : 0);
+        c->sw_prof_n = grid * (CW + 1) * 4 * 2;
 #endif
-    if (second) hipLaunchKernelGGL((svk::k_sweep<N, true, CW>), dim3(grid), dim3(NTHR), lds, c->stream, a);
-    else hipLaunchKernelGGL((svk::k_sweep<N, false, CW>), dim3(grid), dim3(NTHR), lds, c->stream, a);
+        if (second) hipLaunchKernelGGL((svk::k_sweep<N, true, CW>), dim3(grid), dim3(NTHR), lds, c->stream, a);
+        else hipLaunchKernelGGL((svk::k_sweep<N, false, CW>), dim3(grid), dim3(NTHR), lds, c->stream, a);
+    }
     return SV_OK;
 }
 template <int CW>
@@ -596,13 +615,22 @@ int sweep_share(const sv_ctx* c, int nb) {
 }
 int launch_sweep(sv_ctx* c, bool second, int nb) {
     c->last_sweep_cw = sweep_cw_for(c, nb);
-    return c->last_sweep_cw == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
+    const int rc = c->last_sweep_cw == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
+    if (rc == SV_OK && second && c->sweep_fault > 0 && c->sw_error) {   // what a band that ran out its bounded wait leaves behind
+        c->sweep_fault--;
+        *c->sw_error = 1;
+    }
+    return rc;
 }
 // a sweep kernel gave up waiting for its neighbour band (never expected; reported at the next sync point)
 int check_sweep_error(sv_ctx* c) {
     if (c->sw_error && *c->sw_error) {
         *c->sw_error = 0;
-        return fail(c, SV_ERR_HIP, "fused sweep kernel timed out waiting for a neighbouring band; results of that call are invalid");
+        // the sweeps rest on workgroups starting in blockIdx order whenever a launch is not fully resident (sv_sweep.hip.h);
+        // a context that has seen them fail once stays on the per-path kernels, which have no such dependence
+        c->sweep_mode = -1;
+        return fail(c, SV_ERR_HIP, "fused sweep kernel timed out waiting for a neighbouring band; results of that call are invalid "
+                                   "(this context uses the per-path kernels from now on: repeat the call)");
     }
     return SV_OK;
 }
@@ -950,12 +978,13 @@ int sv_create(sv_ctx** out, int device, int width, int height, const sv_params* 
     if (const char* e = getenv("SV_SWEEP_MIN_BATCH")) c->sweep_min_batch = atoi(e);
     if (const char* e = getenv("SV_SWEEP_MODE")) c->sweep_mode = atoi(e);
     if (const char* e = getenv("SV_FAN_CHUNK")) c->fan_chunk = atoi(e);
+    if (const char* e = getenv("SV_SWEEP_FAULT")) c->sweep_fault = atoi(e);   // tests: the next n sweep launches report a timeout
     if (const char* e = getenv("SV_SWEEP_CW")) c->sweep_cw = atoi(e) == 7 ? 7 : (atoi(e) == 15 ? 15 : 0);
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("SV_SWEEP_NCU")) c->n_cu = atoi(e) > 0 ? atoi(e) : c->n_cu;  // tests: few groups, many frames each
     HIPCHK(c, hipHostMalloc((void**)&c->sw_error, sizeof(unsigned int), hipHostMallocMapped));
     *c->sw_error = 0;
-    HIPCHK(c, static_scratch_lookup(device));  // this device's copy of the static scratch (sv_filter_speckles_static_dev)
+    HIPCHK(c, static_scratch_lookup(device, &c->static_scratch));  // this device's copy of the static scratch (sv_filter_speckles_static_dev)
     return alloc_core(c, 1, c->prm);
 }
 
@@ -1234,6 +1263,8 @@ int sv_submit_gray_batch_host(sv_ctx* c, int n_frames, const uint8_t* const* lef
     }
     HIPCHK(c, hipEventRecord(b.done, c->down_stream));
     b.busy = true;
+    b.dst.assign(disp16, disp16 + n);
+    b.ds = ds;
     *ticket = (int)(c->next_batch_ticket++ & 0x7FFFFFFF);
     return SV_OK;
 }
@@ -1247,7 +1278,18 @@ int sv_wait_batch_host(sv_ctx* c, int ticket) {
     DevGuard g(c->device);
     HIPCHK(c, hipEventSynchronize(b.done));
     b.busy = false;
-    return check_sweep_error(c);
+    if (check_sweep_error(c) != SV_OK) {
+        // The batch's inputs are still in the slot's device buffers: run it again, now on the per-path kernels
+        // (check_sweep_error switched the context over), and bring the results down on the compute stream.
+        const size_t W = c->W, H = c->H, n = b.dst.size();
+        int rc = run_sgm(c, (const uint8_t*)b.in_l.p, (const uint8_t*)b.in_r.p, (int16_t*)b.out.p, (int)n);
+        if (rc) return rc;
+        for (size_t i = 0; i < n; i++)
+            HIPCHK(c, copy2d(b.dst[i], b.ds, (const int16_t*)b.out.p + i * W * H, 2 * W, 2 * W, H, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return check_sweep_error(c);
+    }
+    return SV_OK;
 }
 
 int sv_host_alloc(void** ptr, size_t bytes) {
@@ -1456,11 +1498,10 @@ int sv_filter_speckles_static_dev(sv_ctx* c, int16_t* d16, int max_size, int max
     if (npx > (size_t)SV_STATIC_MAX_PIXELS)
         return fail(c, SV_ERR_UNSUPPORTED, "sv_filter_speckles_static_dev: %dx%d = %zu pixels exceed the static scratch of %d pixels; use sv_filter_speckles_dev",
                     c->W, c->H, npx, SV_STATIC_MAX_PIXELS);
-    if (c->device < 0 || c->device >= MAX_DEVICES || !g_scratch_dev[c->device])
-        return fail(c, SV_ERR_HIP, "no static scratch address for device %d", c->device);
+    if (!c->static_scratch) return fail(c, SV_ERR_HIP, "no static scratch address for device %d", c->device);
     DevGuard g(c->device);
     if (!g.ok) return fail(c, SV_ERR_HIP, "hipSetDevice(%d) failed", c->device);
-    int* const lab = g_scratch_dev[c->device];   // never the symbol's name: that is not a device address in host code
+    int* const lab = c->static_scratch;   // looked up in sv_create; never the symbol's name: that is not a device address in host code
     return speckle_launch(c, d16, lab, lab + SV_STATIC_MAX_PIXELS, c->W, c->H, max_size, max_diff, 1, c->stream);
 }
 
@@ -2017,7 +2058,15 @@ int sv_pool_compute_gray_host(sv_pool* p, int n_frames, const uint8_t* const* le
             const int f0 = chunk * batch, n = std::min(batch, n_frames - f0);
             int t = -1;
             rcs[k] = sv_submit_gray_batch_host(c, n, left + f0, ls, right + f0, rs, disp16 + f0, ds, &t);
-            if (rcs[k] != SV_OK) break;
+            if (rcs[k] != SV_OK) {
+                // a submit that failed half-way may have queued copies or kernels without a ticket to wait on: nothing of
+                // this context may still read the caller's buffers or write disp16 when the call returns
+                (void)hipSetDevice(c->device);
+                if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+                (void)hipStreamSynchronize(c->stream);
+                if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
+                break;
+            }
             tickets[(head + in_flight) % SV_BATCH_SLOTS] = t;
             in_flight++;
         }
@@ -2029,8 +2078,16 @@ int sv_pool_compute_gray_host(sv_pool* p, int n_frames, const uint8_t* const* le
         }
     };
     std::vector<std::thread> threads;
-    for (int k = 1; k < n_ctx; k++) threads.emplace_back(work, k);
+    std::vector<int> inline_ctx;   // contexts whose thread could not be started: served by the calling thread afterwards
+    for (int k = 1; k < n_ctx; k++) {
+        try {   // std::thread's constructor throws std::system_error when the process is out of threads: not through a C ABI
+            threads.emplace_back(work, k);
+        } catch (...) {
+            inline_ctx.push_back(k);
+        }
+    }
     work(0);   // the calling thread serves context 0
+    for (int k : inline_ctx) work(k);
     for (auto& t : threads) t.join();
     for (int k = 0; k < n_ctx; k++)
         if (rcs[k] != SV_OK) {

@@ -231,3 +231,45 @@ def test_two_contexts_sweep_concurrently(gpu):
         for i in range(nb):
             assert np.array_equal(got[i], refs[i % nd]), "frame %d differs" % i
         m.close()
+
+
+def test_sweep_timeout_falls_back_to_per_path_kernels(gpu):
+    """a sweep that times out on its neighbour band (injected here: SV_SWEEP_FAULT makes the next sweep launch
+    leave the error word a timed-out band would) must not cost the caller the batch.  Device entry point: sv_synchronize
+    reports it once and the context stays on the per-path kernels; the repeated call is bit-exact.  Batch-through-host entry
+    point: sv_wait_batch_host reruns the batch from the slot's device buffers itself and returns the right frames."""
+    import torch
+    W, H, D, nb, nd = 320, 240, 64, 40, 4
+    ph, po = _params(D, 8)
+    pairs = [synth.stereo_pair(1700 + i, W, H, D) for i in range(nd)]
+    refs = _oracle_many(pairs, po)
+    lefts = np.stack([pairs[i % nd][0] for i in range(nb)])
+    rights = np.stack([pairs[i % nd][1] for i in range(nb)])
+    # (a) device-resident batch
+    m = _matcher_with_env(W, H, ph, SV_SWEEP_FAULT=1)
+    m.set_batch(nb)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    lt, rt = torch.from_numpy(lefts).cuda(), torch.from_numpy(rights).cuda()
+    out = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    assert m.last_aggregation()[1] == 2, "the fused sweeps should have run"
+    with pytest.raises(svhip.SvError) as e:
+        m.synchronize()
+    assert "per-path" in str(e.value)
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    m.synchronize()
+    assert m.last_aggregation()[1] == 0, "after a sweep timeout the context must stay off the sweeps"
+    got = out.cpu().numpy()
+    for i in range(nb):
+        assert np.array_equal(got[i], refs[i % nd]), "frame %d differs" % i
+    m.close()
+    # (b) batch through host buffers: the wait retries by itself
+    m = _matcher_with_env(W, H, ph, SV_SWEEP_FAULT=1)
+    m.set_batch(nb)
+    outs = np.full((nb, H, W), -32768, np.int16)
+    t = m.submit_gray_batch([lefts[i] for i in range(nb)], [rights[i] for i in range(nb)], [outs[i] for i in range(nb)])
+    m.wait_batch(t)
+    assert m.last_aggregation()[1] == 0
+    for i in range(nb):
+        assert np.array_equal(outs[i], refs[i % nd]), "frame %d differs" % i
+    m.close()

@@ -30,7 +30,13 @@ def test_static_scratch_speckle_matches_allocating_entry_point(gpu):
         m.set_stream(stream)
         a = torch.from_numpy(d.copy()).cuda()
         b = torch.from_numpy(d.copy()).cuda()
+        # the property the entry point exists for: the call allocates nothing (the context has no speckle scratch
+        # of its own yet: sv_filter_speckles_dev below is what would allocate it)
+        m.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
         m.filter_speckles_static_dev(a, max_size, max_diff)   # static scratch: no allocation
+        m.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before, "sv_filter_speckles_static_dev changed the free device memory"
         m.filter_speckles_dev(b, max_size, max_diff)          # scratch allocated by the context
         m.synchronize()
         got, exp = a.cpu().numpy(), b.cpu().numpy()
