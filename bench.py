@@ -64,7 +64,17 @@ def cpu_baseline(W, H, D, paths, left, right, budget_s=10.0, threads=16):
         if el > budget_s:
             break
     per_frame = el / n
-    out = {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    out = {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
+           "host_cpus": os.cpu_count(),
            "sample": "%d frames of %dx%d D=%d %d-path SGBM in %.1f s, oracle/libsv_ref.so (restated SGBM; OpenCV not "
                      "installed), single thread" % (n, W, H, D, paths, el)}
     try:
@@ -219,11 +229,14 @@ def main():
         rng = np.random.default_rng(seed0)
         lsrc = [synth.rgb_from_gray(rng, lefts[i]) for i in range(n_distinct)]
         rsrc = [synth.rgb_from_gray(rng, rights[i]) for i in range(n_distinct)]
+        cams = [synth.camera(W, H, i) for i in (0, 1)]
+        # the synthetic pairs are row-aligned: what gets rectified is the two cameras' raw views of them
+        raw = [synth.raw_pair(lsrc[i], rsrc[i], cams) for i in range(n_distinct)]
+        lsrc, rsrc = [r_[0] for r_ in raw], [r_[1] for r_ in raw]
         lrgb = torch.from_numpy(np.stack([lsrc[i % n_distinct] for i in range(B)])).cuda()
         rrgb = torch.from_numpy(np.stack([rsrc[i % n_distinct] for i in range(B)])).cuda()
-        cams = [synth.camera(W, H, i) for i in (0, 1)]
-        for i in (0, 1):   # the synthetic pairs are already row-aligned: both views get the left camera's model
-            m.init_rectify_map(i, *cams[0])
+        for i in (0, 1):
+            m.init_rectify_map(i, *cams[i])
         m.update_mapper(0, *cams[0])
         fpx, base = 0.7 * W, 0.068
         Q = np.array([[1, 0, 0, -(W / 2 - 0.5)], [0, 1, 0, -(H / 2 - 0.5)], [0, 0, 0, fpx], [0, 0, 1 / base, 0]], np.float64)
@@ -345,7 +358,7 @@ def main():
         frame_bytes = m.algorithmic_bytes(4)
         per_path_gbs = 3 * V * B * n_paths / (sum(agg_ms) * 1e-3) / 1e9
         res = {
-            "metric": "disparity frames/sec per GPU at 640x480, D=128, 8 paths; % HBM roofline",
+            "metric": "disparity frames/sec per GPU at %dx%d, D=%d, %d paths; %% HBM roofline" % (W, H, D, paths),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",

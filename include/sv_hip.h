@@ -424,6 +424,19 @@ int sv_last_aggregation(const sv_ctx* ctx, int* n_launches, int* n_fused_sweeps)
  * rocprofv3 trace.  For bench.py; no reference counterpart.                                       */
 int sv_last_sweep_waves(const sv_ctx* ctx);
 
+/* Diagnosis of the one assumption the fused sweeps make about the runtime when a launch is not fully resident
+ * (sv_sweep.hip.h): workgroup i is given to XCD i mod 8, and every XCD starts its workgroups in blockIdx order (a band
+ * waits for the band above it, which has the next lower blockIdx and therefore sits on the previous XCD).  With
+ * enable != 0 every later sweep launch records the start time of each workgroup; the call returns, for the launches
+ * recorded since the previous call: their number; the number of workgroups that started more than 20 us BEFORE workgroup
+ * blockIdx - 8, their predecessor on the same XCD (expected: 0); the largest such lead in ticks of the 100 MHz
+ * s_memrealtime counter (<= 0: none); and, for information, the largest lead over workgroup blockIdx - 1, which is on
+ * another XCD (100+ us in an oversubscribed launch is normal).  It synchronises the context's stream.  A runtime that
+ * breaks the rule is thereby named, not just timed out (SV_ERR_HIP from sv_synchronize after 2 s).  No reference
+ * counterpart (bova_sgm.cu:108-127 launches independent blocks). */
+int sv_debug_sweep_order(sv_ctx* ctx, int enable, int* launches, int* violations, long long* worst_lead_ticks,
+                         long long* worst_lead_prev_ticks);
+
 /* Algorithmic bytes per frame of the current geometry:
  * which: 0 cost, 1 aggregation, 2 wta, 3 tail, 4 frame.                       */
 int64_t sv_algorithmic_bytes(const sv_ctx* ctx, int which);

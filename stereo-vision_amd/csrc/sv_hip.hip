@@ -112,6 +112,10 @@ struct sv_ctx {
     Buf Lbuf[8];
     int fanout_mode = 0;               // 0 auto, 1 always, -1 never
     int fan_chunk = 0;                 // frames per all-paths launch (SV_FAN_CHUNK); 0: from the geometry
+    bool order_check = false;          // sv_debug_sweep_order(ctx, 1, ...): sweep workgroups stamp their start time
+    Buf sw_starts;
+    int sw_starts_n = 0, order_launches = 0, order_violations = 0;
+    long long order_worst = 0, order_worst_prev = 0;
     int sweep_fault = 0;               // fault injection for tests (SV_SWEEP_FAULT): sweep launches left that report a timeout
     int last_agg_launches = 0, last_agg_sweeps = 0;  // of the most recent compute call (sv_last_aggregation)
     int last_sweep_cw = 0;             // compute waves per workgroup of the most recent sweep launch (sv_last_sweep_waves)
@@ -480,6 +484,31 @@ void launch_wta(sv_ctx* c, int nb) {
 
 // One fused sweep (four paths) over nb frames.  second = false: paths R, DR, D, DL, S is written;
 // second = true: paths L, UL, U, UR on mirrored coordinates, S is read, WTA records are written.
+// Dispatch-order check (sv_debug_sweep_order): reads back the start stamps of the last checked sweep launch.  The rule
+// the oversubscribed case rests on (sv_sweep.hip.h): workgroup i goes to XCD i mod 8 and every XCD starts ITS workgroups
+// in blockIdx order.  Counted: workgroups that started more than SW_ORDER_TOL ticks (100 MHz) before workgroup i - 8,
+// their predecessor on the same XCD.  (Against workgroup i - 1, which sits on another XCD, leads of 100+ us are normal
+// in an oversubscribed launch: measured, tests/test_gpu_sweep.py.)
+constexpr long long SW_ORDER_TOL = 2000;   // 20 us: workgroups dispatched together start within microseconds of each other
+constexpr int SW_N_XCD = 8;                // gfx950: 8 XCDs of 32 CUs
+int sweep_order_collect(sv_ctx* c) {
+    if (c->sw_starts_n <= 0 || !c->sw_starts.p) return SV_OK;
+    std::vector<unsigned long long> st((size_t)c->sw_starts_n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(st.data(), c->sw_starts.p, st.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 1; i < st.size(); i++) {
+        const long long lead1 = (long long)st[i - 1] - (long long)st[i];   // > 0: i started before i - 1 (another XCD)
+        if (lead1 > c->order_worst_prev) c->order_worst_prev = lead1;
+        if (i < (size_t)SW_N_XCD) continue;
+        const long long lead = (long long)st[i - SW_N_XCD] - (long long)st[i];   // > 0: i started before its XCD's previous workgroup
+        if (lead > SW_ORDER_TOL) c->order_violations++;
+        if (lead > c->order_worst) c->order_worst = lead;
+    }
+    c->order_launches++;
+    c->sw_starts_n = 0;
+    return SV_OK;
+}
+
 template <int N, int CW>
 int launch_sweep_n(sv_ctx* c, bool second, int nb) {
     constexpr int ROWS = 4 * CW, NTHR = (CW + 1) * 64;
@@ -540,6 +569,14 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
         a.P2P2 = (uint32_t)c->prm.P2 * 0x10001u;
         a.uniq = c->prm.uniqueness_ratio;
         a.n_frames = nf; a.n_groups = n_groups; a.n_bands = n_bands; a.ho_px = ho_px; a.fpg = fpg;
+        a.starts = nullptr;
+        if (c->order_check) {
+            if ((rc = ensure(c, c->sw_starts, (size_t)grid * 8))) return rc;
+            // the previous launch's stamps (same stream, finished by now) are judged before they are overwritten
+            if ((rc = sweep_order_collect(c))) return rc;
+            a.starts = (unsigned long long*)c->sw_starts.p;
+            c->sw_starts_n = grid;
+        }
         a.prof = nullptr;
 #ifdef SV_SWEEP_PROF
         if ((rc = ensure(c, c->sw_prof, (size_t)grid * (CW + 1) * 4 * 8 * 2))) return rc;
@@ -1854,6 +1891,21 @@ int sv_debug_sweep_prof(sv_ctx* c, unsigned long long* out, int n) {
     return c->sw_prof_n;
 }
 #endif
+
+int sv_debug_sweep_order(sv_ctx* c, int enable, int* launches, int* violations, long long* worst_lead_ticks, long long* worst_lead_prev_ticks) {
+    if (!c) return SV_ERR_INVALID_ARG;
+    DevGuard g(c->device);
+    int rc = sweep_order_collect(c);   // the launch still pending, if any
+    if (rc) return rc;
+    if (launches) *launches = c->order_launches;
+    if (violations) *violations = c->order_violations;
+    if (worst_lead_ticks) *worst_lead_ticks = c->order_worst;
+    if (worst_lead_prev_ticks) *worst_lead_prev_ticks = c->order_worst_prev;
+    c->order_launches = c->order_violations = 0;
+    c->order_worst = c->order_worst_prev = 0;
+    c->order_check = enable != 0;
+    return SV_OK;
+}
 
 int sv_set_debug(sv_ctx* c, int enable) {
     if (!c) return SV_ERR_INVALID_ARG;

@@ -19,14 +19,20 @@
 // side: MI355X_MICROARCH.md "Valid forms", first row of the table).  Bands of one frame therefore
 // run as a pipeline, 2*60 steps apart, and a workgroup streams its band of frame after frame
 // without draining, so the 2-steps-per-row skew is paid once per launch, not once per frame.
-// Dispatch order: band b waits for band b-1 of its group, which has the next lower blockIdx.  The launch
-// may hold more workgroups than the chip has slots (n_groups * n_bands > resident capacity: after the
-// frames-per-group clamp, with SV_SWEEP_NCU, or when fewer workgroups fit a CU than the host assumed); that
-// is safe as long as workgroups START in blockIdx order, which the hardware dispatcher does for a 1-D grid
-// (observed, not an architectural promise; tests/test_gpu_sweep.py::test_sweep_grid_exceeds_residency
-// runs a grid of four times the capacity).  Every wait is bounded in time (SW_WAIT_TICKS); a timeout sets
-// the host-visible error word, publishes the band as finished so that the launch drains, and
-// sv_synchronize / the *_host entry points report it.
+// Dispatch order: band b waits for band b-1 of its group, which has the next lower blockIdx.  The host sizes
+// a launch to what the chip holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor; more frames = more
+// frames per group or further launches), so alone on the GPU every workgroup is resident and the order in
+// which they start does not matter.  When the launch shares the GPU (another context's or process's
+// kernels) or is oversubscribed on purpose (SV_SWEEP_NCU, tests), what keeps it live is the dispatcher's
+// rule for a 1-D grid: workgroup i goes to XCD i mod 8, and every XCD starts its workgroups in blockIdx
+// order.  Then the unfinished workgroup with the lowest blockIdx is always resident (it was first in its
+// XCD's queue) and waits for nobody that is not finished, so the launch always advances - although a
+// workgroup may start 100+ us before workgroup blockIdx - 1, which sits on another XCD (measured).  The
+// rule is observed, not an architectural promise: tests/test_gpu_sweep.py::test_sweep_grid_exceeds_residency
+// runs a grid of four times the capacity and checks it with sv_debug_sweep_order (start stamps per workgroup).
+// Every wait is bounded in time (SW_WAIT_TICKS); a timeout sets the host-visible error word, publishes the
+// band as finished so that the launch drains, sv_synchronize / the *_host entry points report it and the
+// context goes over to the per-path kernels.
 // The second sweep is the same kernel on coordinates mirrored in x and y; its finished S stays in
 // registers and goes straight into winner-take-all.
 #pragma once
@@ -64,6 +70,7 @@ struct SweepArgs {
     int n_frames, n_groups, n_bands;
     int fpg;                       // frames per group (the last group may hold fewer)
     int ho_px;                     // handoff pixels per (group, band): frames-per-group * W1, rounded up
+    unsigned long long* starts;    // dispatch-order check (sv_debug_sweep_order): [gridDim.x] s_memrealtime at workgroup start, or nullptr
     unsigned long long* prof;      // diagnostic builds (-DSV_SWEEP_PROF): [gridDim.x][waves][4] cycle sums, else unused
 };
 
@@ -184,6 +191,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     if (SECOND)
         for (int i = tid; i < 2 * SW_ROWS * WSTR; i += NTHR) wta0[i] = 0u;        // well-formed keys (best = 0) before the first real ones
     if (tid == 0) (*abortp) = 0;
+    if (a.starts != nullptr && tid == 0) a.starts[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     // Band 0 has no row above: its import ring is never written, so fill it once with the record
     // of a path start (L = 0, delta = P2) and the first image row needs no special case.
     if (band == 0)

@@ -130,3 +130,56 @@ def camera(W, H, which=0):
         R = rodrigues([-0.005, 0.01, -0.0025])
         P = np.array([[f, 0, cx, -0.068 * f], [0, f, cy, 0], [0, 0, 1, 0]], np.float64)
     return K, dist, R, P
+
+
+def rectified_coords(K, dist, R, P, W, H, iters=30):
+    """For every pixel of a camera's RAW image, where it lies in the rectified image: the pixel is normalised with K, the
+    distortion model (k1 k2 p1 p2 k3 k4 k5 k6) is inverted by fixed-point iteration, then R and the 3x3 part of P are
+    applied - what cv::undistortPoints does for the mapper (stereoCamera.cpp:2462).  Test-scene construction only
+    (numpy, float64): the product's mapper is k_undistort_grid, checked against the oracle's."""
+    k = np.zeros(8)
+    d = np.asarray(dist, np.float64).ravel()
+    k[:d.size] = d
+    k1, k2, p1, p2, k3, k4, k5, k6 = k
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    x0, y0 = (xx - K[0, 2]) / K[0, 0], (yy - K[1, 2]) / K[1, 1]
+    x, y = x0.copy(), y0.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        ic = (1 + ((k6 * r2 + k5) * r2 + k4) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x, y = (x0 - dx) * ic, (y0 - dy) * ic
+    X = R[0, 0] * x + R[0, 1] * y + R[0, 2]
+    Y = R[1, 0] * x + R[1, 1] * y + R[1, 2]
+    Z = R[2, 0] * x + R[2, 1] * y + R[2, 2]
+    return P[0, 0] * X / Z + P[0, 2], P[1, 1] * Y / Z + P[1, 2]
+
+
+def sample_bilinear(img, mx, my):
+    """img[H][W][C] u8 sampled at float coordinates (outside the image: 0), rounded to u8."""
+    H, W = img.shape[:2]
+    x0, y0 = np.floor(mx).astype(np.int64), np.floor(my).astype(np.int64)
+    fx, fy = (mx - x0)[..., None], (my - y0)[..., None]
+    src = img.astype(np.float64)
+
+    def tap(yi, xi):
+        ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+        v = src[np.clip(yi, 0, H - 1), np.clip(xi, 0, W - 1)]
+        return v * ok[..., None]
+    out = (tap(y0, x0) * (1 - fx) + tap(y0, x0 + 1) * fx) * (1 - fy) + (tap(y0 + 1, x0) * (1 - fx) + tap(y0 + 1, x0 + 1) * fx) * fy
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def raw_pair(left_rgb, right_rgb, cams):
+    """What the two cameras of `cams` (camera(W, H, 0 / 1)) would have seen for the row-aligned pair to come out of
+    rectification: every raw pixel takes the colour of the point of the ideal rectified image it maps to (config C3,
+    SURVEY 8(d)).  Rectifying the result (initUndistortRectifyMap + remap) gives the pair back up to two bilinear
+    interpolations, so the matcher finds the scene's disparities in it - unlike the row-aligned pair fed through two
+    different distortions, which it mostly cannot match."""
+    H, W = left_rgb.shape[:2]
+    out = []
+    for img, (K, dist, R, P) in zip((left_rgb, right_rgb), cams):
+        mx, my = rectified_coords(K, dist, R, P, W, H)
+        out.append(sample_bilinear(img, mx, my))
+    return out[0], out[1]

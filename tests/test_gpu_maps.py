@@ -59,6 +59,7 @@ def test_full_pipeline_with_generated_maps(gpu):
         setattr(po, f, getattr(ph, f))
     m = svhip.Matcher(W, H, ph)
     cams = [synth.camera(W, H, i) for i in (0, 1)]
+    lrgb, rrgb = synth.raw_pair(lrgb, rrgb, cams)   # what the two cameras see of the row-aligned scene
     for i, cam in enumerate(cams):
         m.init_rectify_map(i, *cam)
     m.update_mapper(0, *cams[0])
@@ -74,11 +75,19 @@ def test_full_pipeline_with_generated_maps(gpu):
     f, b = 0.7 * W, 0.068
     Q = np.array([[1, 0, 0, -(W / 2 - 0.5)], [0, 1, 0, -(H / 2 - 0.5)], [0, 0, 0, f], [0, 0, 1 / b, 0]], np.float64)
     dep = m.depth(w16, None, Q, cams[0][2])
-    edep = svref.depth(w16, svref.undistort_grid(*cams[0], W, H), Q, cams[0][2], alias=False)
+    assert (got[:, D:] >= 0).mean() > 0.9, "rectification should give a pair the matcher resolves"
+    mapper = svref.undistort_grid(*cams[0], W, H)
+    edep = svref.depth(w16, mapper, Q, cams[0][2], alias=False)
+    # every pixel <= 1e-4 relative, except where the oracle's mapper lies within 2e-4 px (the GPU mapper's tolerance) of a
+    # rounding boundary x.5 and cvRound may pick the neighbouring rectified pixel: named here, under 0.1 % of the image
+    frac = mapper - np.floor(mapper)
+    exempt = (np.abs(frac - 0.5) < 2e-4).any(-1)
+    assert exempt.mean() < 1e-3
     fin = np.isfinite(edep)
-    assert np.array_equal(np.isfinite(dep), fin)
-    rel = np.abs(dep[fin] - edep[fin]) / np.maximum(np.abs(edep[fin]), 1e-12)
-    assert np.quantile(rel, 0.999) <= 1e-4  # a mapper value within 1 ulp of x.5 may round to the other pixel
+    assert np.array_equal(np.isfinite(dep)[~exempt], fin[~exempt])
+    ok = fin & ~exempt
+    rel = np.abs(dep[ok] - edep[ok]) / np.maximum(np.abs(edep[ok]), 1e-12)
+    assert rel.max() <= 1e-4, (rel.max(), int((rel > 1e-4).sum()))
     assert (dep[fin] != 0).mean() > 0.5
     m.close()
 

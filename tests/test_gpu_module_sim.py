@@ -78,13 +78,22 @@ def _expected(D, W, H, rl, rr, wls, blf, mapper, Q, RL):
     return e
 
 
-def _compare(got, exp):
+def _compare(got, exp, mapper=None):
     for k in ("d16", "vis", "d16_blf", "vis_blf", "d16_wls", "vis_wls"):
         assert np.array_equal(got[k], exp[k]), "%s differs in %d pixels" % (k, int((got[k] != exp[k]).sum()))
+    # depth: <= 1e-4 relative (north star) at EVERY pixel, except those the oracle's mapper puts within 2e-4 px (the GPU
+    # mapper's tolerance, tests/test_gpu_maps.py) of a rounding boundary x.5, where depthFromDisparity's cvRound may pick the
+    # neighbouring rectified pixel: these are named by the mask below and must stay under 0.1 % of the image
+    exempt = np.zeros(exp["depth"].shape, bool)
+    if mapper is not None:
+        frac = mapper - np.floor(mapper)
+        exempt = (np.abs(frac - 0.5) < 2e-4).any(-1)
+        assert exempt.mean() < 1e-3, exempt.mean()
     fin = np.isfinite(exp["depth"])
-    assert np.array_equal(np.isfinite(got["depth"]), fin)
-    rel = np.abs(got["depth"][fin] - exp["depth"][fin]) / np.maximum(np.abs(exp["depth"][fin]), 1e-12)
-    assert np.quantile(rel, 0.999) <= 1e-4   # <= 1e-4 relative (north star); a mapper value within 1 ulp of x.5 may round to the other pixel
+    assert np.array_equal(np.isfinite(got["depth"])[~exempt], fin[~exempt])
+    ok = fin & ~exempt
+    rel = np.abs(got["depth"][ok] - exp["depth"][ok]) / np.maximum(np.abs(exp["depth"][ok]), 1e-12)
+    assert rel.max() <= 1e-4, (rel.max(), int((rel > 1e-4).sum()))
 
 
 @pytest.mark.parametrize("wls,blf", [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2)])
@@ -120,12 +129,14 @@ def test_module_call_order_variant_b_c3_full_size(gpu, tmp_path, wls, blf):
     rng = np.random.default_rng(3)
     lrgb, rrgb = synth.rgb_from_gray(rng, left), synth.rgb_from_gray(rng, right)
     cams = [synth.camera(W, H, i) for i in (0, 1)]
+    # what the two (differently distorted) cameras see of the row-aligned scene: rectification gives a matchable pair back
+    lraw, rraw = synth.raw_pair(lrgb, rrgb, cams)
     fx, b = 0.7 * W, 0.068
     Q = np.array([[1, 0, 0, -(W / 2 - 0.5)], [0, 1, 0, -(H / 2 - 0.5)], [0, 0, 0, fx], [0, 0, 1 / b, 0]], np.float64)
-    got, log = _run(tmp_path, W, H, D, wls, blf, lrgb, rrgb, "b", _cam_text(cams, Q))
+    got, log = _run(tmp_path, W, H, D, wls, blf, lraw, rraw, "b", _cam_text(cams, Q))
     maps = [svref.init_rectify_map(*cam, W, H) for cam in cams]
-    rl, rr = svref.remap_rgb(lrgb, *maps[0]), svref.remap_rgb(rrgb, *maps[1])
-    exp = _expected(D, W, H, rl, rr, wls, blf, svref.undistort_grid(*cams[0], W, H), Q, cams[0][2])
-    _compare(got, exp)
-    # (two differently distorted synthetic cameras over a pair that was row-aligned to begin with: a quarter of the pixels match)
-    assert (got["d16"][:, D:] >= 0).mean() > 0.1
+    rl, rr = svref.remap_rgb(lraw, *maps[0]), svref.remap_rgb(rraw, *maps[1])
+    mapper = svref.undistort_grid(*cams[0], W, H)
+    exp = _expected(D, W, H, rl, rr, wls, blf, mapper, Q, cams[0][2])
+    _compare(got, exp, mapper)
+    assert (got["d16"][:, D:] >= 0).mean() > 0.9   # WLS, speckle and depth are checked on a scene the matcher resolves

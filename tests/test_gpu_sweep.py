@@ -138,9 +138,15 @@ def test_sweep_grid_exceeds_residency(gpu, cw):
     m = _matcher_with_env(W, H, ph, SV_SWEEP_NCU=1024, SV_SWEEP_CW=cw)
     m.set_batch(nb)
     m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.sweep_order(True)   # every workgroup stamps its start: the order the hand-off relies on is checked, not assumed
     m.compute_gray_batch_dev(nb, lt, rt, out)
     m.synchronize()   # reports a hand-off timeout
     assert m.last_aggregation() == (2, 2), "the fused sweeps should have run"
+    launches, early, worst, worst_prev = m.sweep_order(False)
+    # the rule: workgroup i -> XCD i mod 8, each XCD in blockIdx order (against blockIdx - 1, on another XCD, a workgroup of
+    # this oversubscribed launch may well start 100+ us early: worst_prev, for the record)
+    print("sweep dispatch order, %d waves: worst lead over blockIdx-8 %d ticks, over blockIdx-1 %d ticks" % (cw, worst, worst_prev))
+    assert launches == 2 and early == 0, "workgroups started before their XCD's previous workgroup: %d of them, by up to %d ticks" % (early, worst)
     got = out.cpu().numpy()
     refs = _oracle_many(pairs, po)
     for i in range(nb):
