@@ -98,10 +98,10 @@ typedef struct sv_params {
                                     x with right x - d - minD, disparity16 = (d + minD) * 16 + sub-pixel, every other pixel is
                                     (minD - 1) * 16 (= SV_INVALID_DISP_SCALED for minD = 0)                                  */
     int32_t num_disparities;     /* D: multiple of 32, 32..256 (DispModule.cpp:1355-1420) */
-    int32_t block_size;          /* SADWindowSize, odd, 1..11                            */
+    int32_t block_size;          /* SADWindowSize, odd, 1..15 (subject to the int16 bound: sv_set_params) */
     int32_t P1;                  /* 8*BS*BS  (StereoMatcher.cpp:279)                     */
     int32_t P2;                  /* 32*BS*BS (StereoMatcher.cpp:280)                     */
-    int32_t pre_filter_cap;      /* 1..63                                                */
+    int32_t pre_filter_cap;      /* 0..127 (2 * cap fits the reference's u8 clip table)  */
     int32_t uniqueness_ratio;    /* 0..100                                               */
     int32_t disp12_max_diff;     /* LR threshold, see SV_FLAG_LR_OPENCV                  */
     int32_t speckle_window_size; /* 0 = off (reference CUDA path has none)               */

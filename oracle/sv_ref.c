@@ -243,9 +243,9 @@ int svref_check_params(const svref_params* p, int W, int H) {
     int D = p->num_disparities, BS = p->block_size;
     if (p->min_disparity < -1024 || p->min_disparity > 1024) return -2; /* (minD - 1) * 16 and (minD + D) * 16 fit int16 */
     if (D < 32 || D > 256 || (D % 32) != 0) return -2;
-    if (BS < 1 || BS > 11 || (BS % 2) == 0) return -2;
+    if (BS < 1 || BS > 15 || (BS % 2) == 0) return -2;   /* the GUI offers 3..31 (cvgui.cpp:100); beyond 15 no cap leaves C inside int16 */
     if (H < BS || geo_w1(W, D, p->min_disparity) < BS || geo_w1(W, D, p->min_disparity) < 1) return -1;
-    if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63) return -2;
+    if (p->pre_filter_cap < 0 || p->pre_filter_cap > 127) return -2;   /* clip(v) + cap is stored in a PixType (u8, costs.cu:286-292): 2 * cap <= 255; the GUI offers 0..100 (cvgui.cpp:102) */
     if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return -2;
     /* max per-pixel BT cost: 2*cap (gradient channel) + 255>>2 (raw channel), per colour channel */
     const int cn = (p->flags & SVREF_FLAG_COST_RGB) ? 3 : 1;

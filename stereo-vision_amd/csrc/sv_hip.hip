@@ -189,19 +189,20 @@ int check_params(sv_ctx* c, const sv_params* p, int W, int H) {
         return fail(c, SV_ERR_UNSUPPORTED, "min_disparity must be in [-1024, 1024] (got %d)", p->min_disparity);
     if (D < 32 || D > 256 || (D % 32) != 0)
         return fail(c, SV_ERR_UNSUPPORTED, "num_disparities must be a multiple of 32 in [32,256] (got %d)", D);
-    if (BS < 1 || BS > 11 || (BS % 2) == 0)
-        return fail(c, SV_ERR_UNSUPPORTED, "block_size must be odd in [1,11] (got %d)", BS);
+    if (BS < 1 || BS > 15 || (BS % 2) == 0)   // the module's GUI offers 3..31 (cvgui.cpp:100); even sizes: SURVEY A9b; beyond 15 the int16 test below fails for any cap
+        return fail(c, SV_ERR_UNSUPPORTED, "block_size must be odd in [1,15] (got %d)", BS);
     // width: the LR check keeps one 4-byte key per column of a row in LDS (160 KB)
     if (D >= 32 && D <= 256 && (geo_w1(W, *p) < 1 || H < BS || geo_w1(W, *p) < BS || W > 40000 || H > 65535))
         return fail(c, SV_ERR_INVALID_ARG, "image %dx%d too small/large for D=%d min_disparity=%d block=%d (W <= 40000, H <= 65535)", W, H, D,
                     p->min_disparity, BS);
-    if (p->pre_filter_cap < 1 || p->pre_filter_cap > 63)
-        return fail(c, SV_ERR_UNSUPPORTED, "pre_filter_cap must be in [1,63] (got %d)", p->pre_filter_cap);
+    // clip(v) + cap lives in a byte (PixType, costs.cu:286-292): 2 * cap <= 255.  The GUI offers 0..100 (cvgui.cpp:102).
+    if (p->pre_filter_cap < 0 || p->pre_filter_cap > 127)
+        return fail(c, SV_ERR_UNSUPPORTED, "pre_filter_cap must be in [0,127] (got %d)", p->pre_filter_cap);
     if (p->P1 < 0 || p->P2 < p->P1 || p->P2 < 1) return fail(c, SV_ERR_INVALID_ARG, "need 0 <= P1 <= P2, P2 >= 1");
     const int cn = (p->flags & SV_FLAG_COST_RGB) ? 3 : 1;
     const long cmax = (long)cn * (2 * p->pre_filter_cap + 63) * BS * BS + p->P2;
     if (cmax > 32767 || (long)p->P1 + 32767 > 65535)
-        return fail(c, SV_ERR_UNSUPPORTED, "cost range overflows int16 (max C = %ld): reduce block_size/P2", cmax);
+        return fail(c, SV_ERR_UNSUPPORTED, "cost range overflows int16 (max C = %d x (2 x cap + 63) x block^2 + P2 = %ld > 32767; the reference would wrap silently): reduce block_size, pre_filter_cap or P2", cn, cmax);
     if (p->uniqueness_ratio < 0 || p->uniqueness_ratio > 100)
         return fail(c, SV_ERR_INVALID_ARG, "uniqueness_ratio must be in [0,100]");
     if ((p->path_mask & 0xFFu) == 0 || (p->path_mask & ~0xFFu)) return fail(c, SV_ERR_INVALID_ARG, "bad path_mask 0x%x", p->path_mask);

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
 #pragma unroll
                 for (int t = 0; t < TAPS; t++)
 #pragma unroll
-                    for (int k = 0; k < N; k++) hs[k] += v[t][k];  // <= 189 * 11 per half: no carry
+                    for (int k = 0; k < N; k++) hs[k] += v[t][k];  // <= (2 cap + 63) * 15 <= 4755 per half: no carry
                 store_regs<N>(myring + (ry % ringn) * (TX * D2), hs);
                 if (ry <= r_init_end) {
                     const uint32_t mult = ry == 0 ? (uint32_t)(radius - ys + 1) : 1u;  // row 0 stands for every row above it
@@ -486,7 +486,9 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
         case 2: run(std::integral_constant<int, 5>{}); break;
         case 3: run(std::integral_constant<int, 7>{}); break;
         case 4: run(std::integral_constant<int, 9>{}); break;
-        default: run(std::integral_constant<int, 11>{}); break;
+        case 5: run(std::integral_constant<int, 11>{}); break;
+        case 6: run(std::integral_constant<int, 13>{}); break;
+        default: run(std::integral_constant<int, 15>{}); break;
     }
 }
 

@@ -35,10 +35,32 @@ void StereoMatcherNew::updateHIPParams() {
     const Params& p = stereo_parameters;
     sv_default_params(&hip_params, p.numberOfDisparities, paths);
     hip_params.min_disparity = p.minDisparity;
-    hip_params.block_size = p.SADWindowSize;
-    hip_params.P1 = 8 * p.SADWindowSize * p.SADWindowSize;
-    hip_params.P2 = 32 * p.SADWindowSize * p.SADWindowSize;
-    hip_params.pre_filter_cap = p.preFilterCap;
+    // The GUI / RPC offer SADWindowSize 3..31 in steps of 1 and preFilterCap 0..100 (cvgui.cpp:100,102); the library takes odd
+    // blocks up to 15 and caps up to 127 as long as no cost leaves int16 ((2 cap + 63) BS^2 + P2 <= 32767: beyond that the
+    // reference's CostType wraps silently).  What lies outside is brought inside here and said so, instead of leaving the
+    // module on its previous parameters:
+    //  * an even size b: cv::StereoSGBM's window is 2 (b / 2) + 1 = b + 1 wide while matchSGBM's P1, P2 keep b (StereoMatcher.cpp:402-403)
+    //  * a size or cap too large for int16: the largest block that fits with this cap, P1 / P2 following it
+    int bs = p.SADWindowSize < 1 ? 1 : p.SADWindowSize, pbs = bs;   // pbs: the size P1 / P2 are computed from
+    if ((bs & 1) == 0) {
+        bs += 1;
+        std::cout << "[StereoMatcherNew] sgbm_hip: even SADWindowSize " << pbs << " -> window " << bs << " (as cv::StereoSGBM), P1/P2 from " << pbs << std::endl;
+    }
+    int cap = p.preFilterCap < 0 ? 0 : (p.preFilterCap > 127 ? 127 : p.preFilterCap);
+    if (cap != p.preFilterCap) std::cout << "[StereoMatcherNew] sgbm_hip: preFilterCap " << p.preFilterCap << " -> " << cap << std::endl;
+    const int cn = 1;   // gray cost (x3 with SV_FLAG_COST_RGB, which the module mirror does not set)
+    auto fits = [&](int b, int pb) { return b <= 15 && (long)cn * (2 * cap + 63) * b * b + 32L * pb * pb <= 32767; };
+    if (!fits(bs, pbs)) {
+        const int asked = bs;
+        while (bs > 1 && !fits(bs, bs < pbs ? bs : pbs)) bs -= 2;
+        if (bs < pbs) pbs = bs;
+        std::cout << "[StereoMatcherNew] sgbm_hip: SADWindowSize " << asked << " with preFilterCap " << cap
+                  << " would overflow the int16 costs: using " << bs << std::endl;
+    }
+    hip_params.block_size = bs;
+    hip_params.P1 = 8 * pbs * pbs;
+    hip_params.P2 = 32 * pbs * pbs;
+    hip_params.pre_filter_cap = cap;
     hip_params.uniqueness_ratio = p.uniquenessRatio;
     hip_params.disp12_max_diff = p.disp12MaxDiff;
     // the CPU path filters speckles inside cv::StereoSGBM::compute; the CUDA path has no such stage

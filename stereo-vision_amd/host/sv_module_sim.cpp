@@ -12,6 +12,7 @@
 //   --cam FILE    text: for left and right n_dist K(9) dist(n_dist) Rrect(9) Prect(12), then Q(16)
 //   --out FILE    raw dump of the last frame: d16 base, vis base, d16 blf, vis blf, d16 wls, vis wls, depth (float)
 //   --breakdown   per-call host wall time (mean over the timed frames)
+//   --sad N --cap N   SADWindowSize / preFilterCap as the GUI or RPC would set them (defaults 7 / 63, DispModule.cpp:369-394)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +61,7 @@ int main(int argc, char** argv) {
     int npos = 0;
     std::string mode = "a", in_file, cam_file, out_file;
     bool breakdown = false;
+    int sad = 7, cap = 63;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--breakdown") breakdown = true;
@@ -67,6 +69,8 @@ int main(int argc, char** argv) {
         else if (a == "--in" && i + 1 < argc) in_file = argv[++i];
         else if (a == "--cam" && i + 1 < argc) cam_file = argv[++i];
         else if (a == "--out" && i + 1 < argc) out_file = argv[++i];
+        else if (a == "--sad" && i + 1 < argc) sad = atoi(argv[++i]);
+        else if (a == "--cap" && i + 1 < argc) cap = atoi(argv[++i]);
         else if (npos < 7 && (isdigit((unsigned char)a[0]))) pos[npos++] = atoi(a.c_str());
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
     }
@@ -82,7 +86,7 @@ int main(int argc, char** argv) {
     matcher.paths = paths;
     matcher.setAlgorithm("sgbm_hip");  // DispModule.cpp:246-251 keyword
     // DispModule::initializeStereoParams defaults (DispModule.cpp:369-394), numDisp from the CLI
-    matcher.setParameters(0, D, 7, 0, 63, 15, 50, 16, 10.0, 10.0, 4500., 1.0, blf == 1 ? BLF_ORIGINAL : (blf == 2 ? BLF_CUDA : BLF_DISABLED), wls ? WLS_ENABLED : WLS_DISABLED, SGBM_HIP);
+    matcher.setParameters(0, D, sad, 0, cap, 15, 50, 16, 10.0, 10.0, 4500., 1.0, blf == 1 ? BLF_ORIGINAL : (blf == 2 ? BLF_CUDA : BLF_DISABLED), wls ? WLS_ENABLED : WLS_DISABLED, SGBM_HIP);
     matcher.updateHIPParams();
 
     // camera: from the file, or an identity rectification with a plausible Q so that the depth stage runs

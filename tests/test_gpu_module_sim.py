@@ -33,13 +33,13 @@ def _oracle_params(D):
     return po
 
 
-def _run(tmp_path, W, H, D, wls, blf, lrgb, rrgb, mode, cam_text=None):
+def _run(tmp_path, W, H, D, wls, blf, lrgb, rrgb, mode, cam_text=None, extra=()):
     assert os.path.exists(SIM), "host shim not built (make -C stereo-vision_amd/host)"
     fin, fout = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
     with open(fin, "wb") as f:
         f.write(np.ascontiguousarray(lrgb).tobytes())
         f.write(np.ascontiguousarray(rrgb).tobytes())
-    cmd = [SIM, str(W), str(H), str(D), "2", "8", str(wls), str(blf), "--mode", mode, "--in", fin, "--out", fout, "--breakdown"]
+    cmd = [SIM, str(W), str(H), str(D), "2", "8", str(wls), str(blf), "--mode", mode, "--in", fin, "--out", fout, "--breakdown"] + list(extra)
     if cam_text is not None:
         fcam = str(tmp_path / "cam.txt")
         open(fcam, "w").write(cam_text)
@@ -140,3 +140,29 @@ def test_module_call_order_variant_b_c3_full_size(gpu, tmp_path, wls, blf):
     exp = _expected(D, W, H, rl, rr, wls, blf, mapper, Q, cams[0][2])
     _compare(got, exp, mapper)
     assert (got["d16"][:, D:] >= 0).mean() > 0.9   # WLS, speckle and depth are checked on a scene the matcher resolves
+
+
+@pytest.mark.parametrize("sad,cap,block,pblock,ecap,note", [
+    (8, 63, 9, 8, 63, "even SADWindowSize 8 -> window 9"),          # cv::StereoSGBM: window 2 (8 / 2) + 1, P1 / P2 from 8
+    (21, 63, 11, 11, 63, "would overflow the int16 costs: using 11"),  # (2 * 63 + 63) * 13^2 + 32 * 13^2 > 32767
+    (13, 31, 13, 13, 31, None),                                       # fits as asked
+    (7, 100, 7, 7, 100, None),                                        # the GUI's upper cap
+    (7, 200, 7, 7, 127, "preFilterCap 200 -> 127"),
+])
+def test_shim_brings_gui_parameter_ranges_inside(gpu, tmp_path, sad, cap, block, pblock, ecap, note):
+    """cvgui.cpp:100,102 offer SADWindowSize 3..31 (steps of 1) and preFilterCap 0..100: what the library does not take as
+    it stands, the shim's updateHIPParams() maps to the nearest accepted setting and logs; the result is the oracle's for
+    that setting (module defaults otherwise: speckle 50/16, MODE_HH)."""
+    W, H, D = 320, 240, 64
+    left, right, _ = synth.stereo_pair(730 + sad, W, H, D)
+    rng = np.random.default_rng(sad)
+    lrgb, rrgb = synth.rgb_from_gray(rng, left), synth.rgb_from_gray(rng, right)
+    got, log = _run(tmp_path, W, H, D, 0, 0, lrgb, rrgb, "a", extra=["--sad", str(sad), "--cap", str(cap)])
+    po = _oracle_params(D)
+    po.block_size, po.P1, po.P2, po.pre_filter_cap = block, 8 * pblock * pblock, 32 * pblock * pblock, ecap
+    exp = svref.sgbm(svref.gray_from_rgb(lrgb), svref.gray_from_rgb(rrgb), po)
+    assert np.array_equal(got["d16"], exp), int((got["d16"] != exp).sum())
+    assert "rejected" not in log
+    if note:
+        assert note in log, log
+    assert (exp[:, D:] >= 0).mean() > 0.5

@@ -259,3 +259,39 @@ def test_async_batch_host(gpu):
     for a in (pin_l, pin_r, pin_o):
         a.free()
     m.close()
+
+
+@pytest.mark.parametrize("W,H,D,bs,cap,paths", [
+    (200, 60, 64, 13, 31, 8),     # blocks beyond 11 with the caps that keep every cost inside int16
+    (180, 70, 32, 15, 15, 5),
+    (330, 48, 256, 15, 15, 8),    # D = 256: the 16-row ring of a 15 x 15 block needs the 24-column tile to fit the LDS
+    (160, 50, 64, 7, 100, 8),     # the GUI's upper preFilterCap (cvgui.cpp:102)
+    (160, 50, 64, 7, 127, 5),     # the largest cap whose clip table fits a byte
+    (160, 50, 64, 5, 0, 8),       # the GUI's lower end: every gradient clipped to 0
+])
+def test_gui_parameter_ranges_bit_exact(gpu, W, H, D, bs, cap, paths):
+    """SADWindowSize / preFilterCap beyond the module defaults (cvgui.cpp:100,102): cost volume, S and
+    disparity against the oracle, single frame (every aggregation variant) and a small batch."""
+    import torch
+    left, right, _ = synth.stereo_pair(4000 + bs + cap, W, H, D)
+    ph, po = _params(D, paths, block_size=bs, P1=8 * bs * bs, P2=32 * bs * bs, pre_filter_cap=cap)
+    ref, st = svref.sgbm(left, right, po, stages=("C", "S"))
+    m = svhip.Matcher(W, H, ph)
+    for mode in (0, 4, 5, 3):
+        m.set_debug(mode)
+        assert np.array_equal(m.compute_gray(left, right), ref), "debug mode %d" % mode
+    m.set_debug(True)
+    assert np.array_equal(m.compute_gray(left, right), ref)
+    assert np.array_equal(m.debug_volume(0), st["C"]) and np.array_equal(m.debug_volume(1), st["S"])
+    m.set_debug(0)
+    nb = 9   # the batched cost kernel (frame -> XCD order, 64-column tiles where they fit)
+    m.set_batch(nb)
+    lt, rt = torch.from_numpy(np.stack([left] * nb)).cuda(), torch.from_numpy(np.stack([right] * nb)).cuda()
+    out = torch.empty((nb, H, W), dtype=torch.int16, device="cuda")
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.compute_gray_batch_dev(nb, lt, rt, out)
+    m.synchronize()
+    assert all(np.array_equal(o, ref) for o in out.cpu().numpy())
+    m.close()
+    with pytest.raises(svhip.SvError):
+        svhip.Matcher(W, H, svhip.default_params(D, paths, block_size=17, P1=8, P2=32, pre_filter_cap=1))   # beyond 15: refused whatever the cap
