@@ -198,7 +198,7 @@ def main():
     from svhip import synth
 
     W, H, D, paths = CONFIGS[args.config]
-    B = args.batch if args.config != "c4" else min(args.batch, 96)  # C4: 1.84 GB of volumes per pair (96 pairs = 177 GB)
+    B = args.batch if args.config != "c4" else min(args.batch, 98)  # C4: 1.84 GB of volumes per pair (98 pairs = 180 GB = 7 pipelines x 14 frames)
     params = svhip.default_params(D, paths)  # SAD 7, P1 8*49, P2 32*49, cap 63, uniq 15, LR check on
     n_distinct = min(B, 64)   # 64 distinct pairs per stream, looped
     seed0 = 202 if world == 1 else 500 + 64 * rank

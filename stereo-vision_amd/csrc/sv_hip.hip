@@ -591,19 +591,22 @@ int launch_sweep_n(sv_ctx* c, bool second, int nb) {
 }
 template <int CW>
 int launch_sweep_cw(sv_ctx* c, bool second, int nb) {
-    switch (c->prm.num_disparities / 32) {
-        case 1: return launch_sweep_n<1, CW>(c, second, nb);
-        case 2: return launch_sweep_n<2, CW>(c, second, nb);
-        case 3: return launch_sweep_n<3, CW>(c, second, nb);
-        case 4: return launch_sweep_n<4, CW>(c, second, nb);
-        default: break;
-    }
-    if constexpr (CW <= 7) {  // D > 128: 8 waves per workgroup, 256 VGPRs each
+    if constexpr (CW == 8) {
+        // D > 128: 8 compute waves (two per SIMD) + the service wave, 32 rows per band; a lane keeps up to 132 VGPRs, and
+        // 32 rows of 1.6 KB records + the winner-take-all slots are what the 160 KB of LDS hold (sweep_ring)
         switch (c->prm.num_disparities / 32) {
             case 5: return launch_sweep_n<5, CW>(c, second, nb);
             case 6: return launch_sweep_n<6, CW>(c, second, nb);
             case 7: return launch_sweep_n<7, CW>(c, second, nb);
             case 8: return launch_sweep_n<8, CW>(c, second, nb);
+            default: break;
+        }
+    } else {
+        switch (c->prm.num_disparities / 32) {
+            case 1: return launch_sweep_n<1, CW>(c, second, nb);
+            case 2: return launch_sweep_n<2, CW>(c, second, nb);
+            case 3: return launch_sweep_n<3, CW>(c, second, nb);
+            case 4: return launch_sweep_n<4, CW>(c, second, nb);
             default: break;
         }
     }
@@ -629,7 +632,7 @@ double sweep_cost(const sv_ctx* c, int cw, int n) {
     return (double)((n + pipes - 1) / pipes) * W1 * stream + (double)(bands - 1) * (2 * rows + 2) * fill;
 }
 int sweep_cw_for(const sv_ctx* c, int nb) {
-    if (c->prm.num_disparities > 128) return 7;
+    if (c->prm.num_disparities > 128) return 8;
     if (c->sweep_cw) return c->sweep_cw;
     return sweep_cost(c, 7, nb) < sweep_cost(c, 15, nb) ? 7 : 15;
 }
@@ -642,8 +645,9 @@ int sweep_share(const sv_ctx* c, int nb) {
     const double fan_unit = 3.1e-4 * W1 * c->H;
     int best_n = nb;
     double best = sweep_cost(c, sweep_cw_for(c, nb), nb);
-    for (int cw = 7; cw <= 15; cw += 8) {
-        if ((c->prm.num_disparities > 128 && cw == 15) || (c->sweep_cw && cw != c->sweep_cw)) continue;
+    for (int cw = 7; cw <= 15; cw++) {
+        if (cw != 7 && cw != 8 && cw != 15) continue;
+        if ((c->prm.num_disparities > 128) != (cw == 8) || (c->sweep_cw && cw != 8 && cw != c->sweep_cw)) continue;
         const int pipes = sweep_pipes(c, cw), n = nb / pipes * pipes;
         if (n <= 0 || n == nb) continue;
         const double cost = sweep_cost(c, cw, n) + (nb - n) * fan_unit;
@@ -653,7 +657,8 @@ int sweep_share(const sv_ctx* c, int nb) {
 }
 int launch_sweep(sv_ctx* c, bool second, int nb) {
     c->last_sweep_cw = sweep_cw_for(c, nb);
-    const int rc = c->last_sweep_cw == 15 ? launch_sweep_cw<15>(c, second, nb) : launch_sweep_cw<7>(c, second, nb);
+    const int rc = c->last_sweep_cw == 15 ? launch_sweep_cw<15>(c, second, nb)
+                   : (c->last_sweep_cw == 8 ? launch_sweep_cw<8>(c, second, nb) : launch_sweep_cw<7>(c, second, nb));
     if (rc == SV_OK && second && c->sweep_fault > 0 && c->sw_error) {   // what a band that ran out its bounded wait leaves behind
         c->sweep_fault--;
         *c->sw_error = 1;

@@ -40,7 +40,10 @@
 
 namespace svk {
 
-constexpr int SW_RING = 8;    // pixels in the import / export rings (a record is written <= 3 steps before it is read)
+// pixels in the import / export rings: a record is written <= 3 steps before it is read, so 4 are enough; the 9-wave
+// shape for D > 128 takes 4 (its 32 rows of 1.6 KB records leave no room for more), the others 8
+template <int CW>
+__host__ __device__ constexpr int sweep_ring() { return CW == 8 ? 4 : 8; }
 constexpr int SW_LEAD = 32;   // loop steps before stream pixel 0 (service pipeline warm-up), multiple of 4
 #ifndef SV_SW_DEPTH
 #define SV_SW_DEPTH 2
@@ -87,7 +90,7 @@ template <int N>
 __host__ __device__ constexpr int sweep_wta_words() { return 16 * N + 20; }
 template <int N, int CW, bool SECOND>
 __host__ __device__ constexpr size_t sweep_lds_bytes() {
-    return sizeof(uint32_t) * ((size_t)(2 * (4 * CW + 1) + 2 * SW_RING) * sweep_rec_words<N>() + 4 +
+    return sizeof(uint32_t) * ((size_t)(2 * (4 * CW + 1) + 2 * sweep_ring<CW>()) * sweep_rec_words<N>() + 4 +
                                (SECOND ? (size_t)2 * 4 * CW * sweep_wta_words<N>() : 0));
 }
 
@@ -154,7 +157,7 @@ __device__ __forceinline__ void sweep_barrier() {
 
 template <int N, bool SECOND, int CW>
 __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
-    constexpr int SW_ROWS = 4 * CW, NTHR = (CW + 1) * 64;
+    constexpr int SW_ROWS = 4 * CW, NTHR = (CW + 1) * 64, SW_RING = sweep_ring<CW>();
     constexpr int PXW = 16 * N, REC = sweep_rec_words<N>(), RECQ = REC / 2;
     extern __shared__ __align__(16) uint32_t sw_lds[];
     uint32_t* const slot = sw_lds;                              // [2][SW_ROWS + 1][REC]: slot[p][r] is read by row r
@@ -268,9 +271,9 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     int wfi = 0;
     uint32_t wrec = (uint32_t)(H - 1 - min(wyl, H - 1)) * a.W + a.col0;   // record index of the row's first pixel in frame wfi
 
-    static_assert(N >= 1 && (N <= 4 || (N <= 8 && CW <= 7)),
+    static_assert(N >= 1 && (N <= 4 || (N <= 8 && CW <= 8)),
                   "k_sweep keeps four paths of D = 32*N disparities in registers: D <= 128 with 16 waves per workgroup (128 "
-                  "VGPRs each), D <= 256 with 8 (256 VGPRs each)");
+                  "VGPRs each), D <= 256 with 9 (170 VGPRs each; 132 used)");
     const int tau_end = total_px + 2 * SW_ROWS + 4;
     // Two loops with the same trip count and one barrier per step each: the compute waves and the
     // service wave never share a basic block, so each body is straight-line code for the scheduler.
