@@ -415,13 +415,14 @@ int launch_cost2_n(sv_ctx* c, int nb) {
         // Large batches: 64-column tiles (1024 threads, one workgroup per CU) recompute the 2r halo columns of the
         // BT costs for 58 instead of 26 output columns: 27.9 -> 27.2 ms per 1024 frames at C2.  Only where the
         // tile fits the 160 KB of LDS (D <= 128 with blocks up to 7x7) and the launch has enough tiles to go round.
-        if (nb >= 8 && (size_t)(2 * 64 + (2 * r + 2) * (64 - 2 * r)) * (16 * N) * 4 <= 160 * 1024 && c->debug_mode != 4)
+        if (nb >= 8 && 64 - 2 * r >= 16 && svk::cost_lds_bytes<N, 1024, CN>(r) <= 160 * 1024 && c->debug_mode != 4 && !getenv("SV_COST_NT512"))
             return launch_cost2_n<N, CN, 1024>(c, nb);
     }
-    const size_t lds = (size_t)(2 * NCOL + (2 * r + 2) * TX) * (16 * N) * 4;
+    if (TX < 1) return fail(c, SV_ERR_UNSUPPORTED, "block size %d leaves no output column in a %d-column tile", p.block_size, NCOL);
+    const size_t lds = svk::cost_lds_bytes<N, NT, CN>(r);
     if (lds > 160 * 1024) {
-        // D = 256 with an 11 x 11 block: the 12-row ring of a 32-column tile is 164 KB.  24 tile columns fit.
-        if constexpr (NT == 512 && N == 8) return launch_cost2_n<N, CN, 384>(c, nb);
+        // D >= 224 with blocks from 11 x 11: the ring of a 32-column tile passes the 160 KB.  24 tile columns fit.
+        if constexpr (NT == 512 && N >= 7) return launch_cost2_n<N, CN, 384>(c, nb);
         return fail(c, SV_ERR_UNSUPPORTED, "cost kernel tile of %zu bytes exceeds the 160 KB of LDS", lds);
     }
     bool* attr_set = c->attr_cost2[CN == 3][NT == 512 ? 0 : (NT == 384 ? 1 : 2)];  // per context: the attribute is per device

@@ -332,21 +332,51 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // BT phase: the costs of tile column j for its 2N disparities -> LDS; window phase (j < TX): the
 // 2r+1-tap horizontal sum for output column j from LDS, the last 2r+2 sums in a private LDS ring,
 // the vertical running sum in registers, C out with the 16-byte stores k_agg / k_sweep read back.
+#ifndef SV_COST_ABL
+#define SV_COST_ABL 0   // diagnostic builds (wrong results): 1 C to the sink, 2 no stage reads / writes, 4 one window tap, 8 no BT arithmetic, 16 no ring
+#endif
 constexpr int COST_SINK_SLOTS = 256;   // sink slots of NT * N dwords each (workgroup id mod 256)
+// Gray cost (CN = 1): the right-image statistics a tile row needs - NCOL + 32 N - 1 consecutive elements of each of the
+// three reversed planes, 1.2 KB at D = 128 - are staged ONCE per image row in LDS, already unpacked into the u16 pairs the
+// packed VALU wants: [3 statistics a, a0, a1][4 copies][SPANW] pairs of dwords {gradient pair, raw pair}, entry m of copy c =
+// (element 2m + c, element 2m + c + 1) counted from the tile row's first element rounded down to a multiple of 4; a lane
+// whose first element is i0 reads copy i0 mod 4 from an even entry on, i.e. with 16-byte aligned ds_read_b128.  Before, every lane loaded its 3 N packed dwords through
+// L1 (49 KB per tile row for 1.2 KB of distinct data) and spent 6 N instructions unpacking them, per (column, disparity)
+// instead of per element.  Double-buffered by the row's parity.
+template <int N, int NT>
+__host__ __device__ constexpr int cost_stage_spanw() {
+    // entries per copy; = 2 mod 4, so that a copy is 4 mod 8 dwords long and neighbouring columns (which read neighbouring copies)
+    // fall on the other half of every 8 banks in a ds_read_b128 lane group
+    return ((NT / 16 + 32 * N + 8) / 2) % 4 == 0 ? (NT / 16 + 32 * N + 8) / 2 + 2 : (NT / 16 + 32 * N + 8) / 2 + ((NT / 16 + 32 * N + 8) / 2) % 2;
+}
+template <int N, int NT>
+__host__ __device__ constexpr int cost_stage_items() { return (6 * (cost_stage_spanw<N, NT>() + 1) + NT - 1) / NT; }   // global dwords per thread and row
+// ... where it pays: up to D = 128 (measured: 640x480 D=128 24.4 -> 23.8 ms per 1024 frames, 320x240 D=64 5.05 -> 4.65; at D = 256, two
+// waves per SIMD and 222 VGPRs, 38.3 -> 43.4 ms per 98 frames of 1920x1080, so those keep the direct loads)
+template <int N, int CN>
+__host__ __device__ constexpr bool cost_stage() { return CN == 1 && N <= 4; }
+template <int N, int NT, int CN>
+__host__ __device__ constexpr size_t cost_lds_bytes(int radius) {
+    const int NCOL = NT / 16, TX = NCOL - 2 * radius;
+    return ((size_t)(2 * NCOL + (2 * radius + 1) * TX) * (16 * N) + (cost_stage<N, CN>() ? (size_t)2 * 24 * cost_stage_spanw<N, NT>() : 0)) * 4;
+}
 template <int N, int NT, int CN>
 __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
                                                uint32_t* __restrict__ C, int W, int H, int WP, int radius, int yband,
                                                uint32_t P2P2, int tail_p2, int ntx, int nbands, int nframes, int col0, int W1,
                                                int min_disp, uint32_t* __restrict__ sink) {
     constexpr int cn = CN;  // colour planes summed into the cost (1 = gray, 3 = RGB)
+    constexpr bool STAGE = cost_stage<N, CN>();   // right statistics through the LDS stage (cost_stage_spanw); the colour cost and D > 128 keep the direct loads
     extern __shared__ __align__(16) uint32_t c2_lds[];
     constexpr int D2 = 16 * N, NCOL = NT / 16;
+    constexpr int SPANW = cost_stage_spanw<N, NT>(), ITEMS = cost_stage_items<N, NT>(), RSBUF = 24 * SPANW;
     // col0 = first computable column, W1 = their number, min_disp = minDisparity (EXT, cv::StereoSGBM): cost index d
     // pairs left x with right x - d - min_disp; with min_disp = 0 (the CUDA back-end) col0 = D, W1 = W - D
     const int tid = threadIdx.x, j = tid >> 4, q = tid & 15;
-    const int TX = NCOL - 2 * radius, ringn = 2 * radius + 2;
+    const int TX = NCOL - 2 * radius, ringn = 2 * radius + 1;
     uint32_t* const pix = c2_lds;                      // [2][NCOL][D2]
     uint32_t* const ring = pix + 2 * NCOL * D2;        // [ringn][TX][D2]
+    uint32_t* const rs = ring + ringn * TX * D2;       // STAGE: [2][3][4][SPANW] x {gradient pair, raw pair}
     // 1-D grid, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, so id % 8
     // picks the frame within a group of 8 and all column tiles of a frame (whose right-image reads
     // overlap by D + 2r columns) share one XCD's L2.
@@ -373,14 +403,78 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     uint32_t* const mypix = pix + j * D2 + q * N;
     uint32_t* const myring = ring + j * D2 + q * N;
 
+    // ---- the stage.  First element of the tile row: that of its last column (the planes are reversed in x) at d = 0,
+    // rounded down to a multiple of 4.  Item it (0 .. 6 (SPANW + 1)) = (plane, global copy gc, dword mm): global dword
+    // e_lo4 / 2 + mm of copy gc = elements (e_lo4 + 2 mm + gc, + 1) = dword mm of stage copy gc and dword mm - 1 of copy gc + 2.
+    const int xj_max = min(max(xl0 - radius + NCOL - 1, 0), W1 - 1) + col0;
+    const int e_lo4 = ((W - 1 - xj_max) + min_disp) & ~3;
+    const int i0 = e - e_lo4;                            // this lane's first element within the stage
+    const uint32_t* const myrs = rs + 2 * ((i0 & 3) * SPANW + ((i0 - (i0 & 3)) >> 1));   // + statistic * 8 * SPANW + parity * RSBUF
+    uint32_t sv[ITEMS];        // staged dwords in flight (one image row ahead of the stage's contents)
+    size_t sv_src[ITEMS];      // their dword offset in row 0 of the planes (plane and copy included, clamped into the row's pitch)
+    int sv_dst[ITEMS];         // stage entry, copy gc: (plane * 4 + gc) * SPANW + mm
+    int sv_mm[ITEMS];          // mm, or -1: this thread has no such item
+    if (STAGE) {
+#pragma unroll
+        for (int t = 0; t < ITEMS; t++) {
+            const int it = min(tid + t * NT, 6 * (SPANW + 1) - 1);
+            const int plc = it / (SPANW + 1), mm = it - plc * (SPANW + 1);   // plc = 2 * plane + global copy
+            sv_src[t] = (size_t)plc * plane + (size_t)min(e_lo4 / 2 + mm, WP / 2 - 1);   // (past the row's pitch: a value nobody reads)
+            sv_dst[t] = ((plc >> 1) * 4 + (plc & 1)) * SPANW + mm;
+            sv_mm[t] = tid + t * NT < 6 * (SPANW + 1) ? mm : -1;
+            sv[t] = 0;
+        }
+    }
+    // every thread loads (those without an item repeat the last one): no vector memory operation behind a condition
+    auto stage_load = [&](int ry) {
+        const uint32_t* rowp = rp32 + (size_t)min(ry, H - 1) * (WP / 2);
+#pragma unroll
+        for (int t = 0; t < ITEMS; t++) sv[t] = rowp[sv_src[t]];
+    };
+    auto stage_write = [&](int par) {
+        uint32_t* const dstb = rs + par * RSBUF;
+#pragma unroll
+        for (int t = 0; t < ITEMS; t++) {
+            const uint32_t g = sv[t] & 0x00FF00FFu, r = __builtin_amdgcn_perm(0u, sv[t], 0x0C030C01u);
+            const int d0 = sv_dst[t], mm = sv_mm[t];
+            if (mm >= 0 && mm < SPANW) *reinterpret_cast<uint2*>(dstb + 2 * d0) = make_uint2(g, r);                    // copy gc, entry mm
+            if (mm >= 1) *reinterpret_cast<uint2*>(dstb + 2 * (d0 + 2 * SPANW - 1)) = make_uint2(g, r);                 // copy gc + 2, entry mm - 1
+        }
+    };
+
+    // the lane's right statistics of the NEXT row to be costed, as u16 pairs (g, g0, g1, r, r0, r1), read from the stage one
+    // trip ahead so that the costs start from registers and the reads' latency lies under the window sums
+    uint32_t st[6][N];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; s6++)
+#pragma unroll
+        for (int k = 0; k < N; k++) st[s6][k] = 0;
+    auto stage_read = [&](int par) {
+        const uint32_t* src = myrs + par * RSBUF;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; s3++) {
+            // 16-byte aligned by construction (copy = first element mod 4, so the first entry is even): two entries per read
+#pragma unroll
+            for (int k = 0; k + 1 < N; k += 2) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src + s3 * 8 * SPANW + 2 * k);
+                st[s3][k] = v.x; st[3 + s3][k] = v.y; st[s3][k + 1] = v.z; st[3 + s3][k + 1] = v.w;
+            }
+            if (N & 1) {
+                const uint2 v = *reinterpret_cast<const uint2*>(src + s3 * 8 * SPANW + 2 * (N - 1));
+                st[s3][N - 1] = v.x; st[3 + s3][N - 1] = v.y;
+            }
+        }
+    };
     uint2 lrec;
-    uint32_t rq[3][N];  // right statistics as loaded: per u16 the gradient statistic in the low byte, the raw one in the high byte
+    uint32_t rq[3][N];  // !STAGE: right statistics as loaded: per u16 the gradient statistic in the low byte, the raw one in the high byte
     auto prefetch = [&](int ry, int ch) {
         ry = min(ry, H - 1);
         lrec = stat_l[(size_t)ch * W * H + (size_t)ry * W + xj];
+        if (!STAGE) {
 #pragma unroll
-        for (int s3 = 0; s3 < 3; s3++)
-            load_regs<N>(rbase + (size_t)(6 * ch + 2 * s3) * plane + (size_t)ry * (WP / 2), rq[s3]);
+            for (int s3 = 0; s3 < 3; s3++)
+                load_regs<N>(rbase + (size_t)(6 * ch + 2 * s3) * plane + (size_t)ry * (WP / 2), rq[s3]);
+        }
     };
     // BT costs of image row ry, summed over the cn colour planes (operands of plane 0 in lrec / rq,
     // prefetched) -> pix[ry & 1]; while a plane is computed the operands of the next plane, or of
@@ -396,10 +490,17 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
             const uint32_t ur0 = (lrec.y & 0xFFu) * 0x10001u, ur1 = ((lrec.y >> 8) & 0xFFu) * 0x10001u;
 #pragma unroll
             for (int k = 0; k < N; k++) {  // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
-                // unpack: one v_and / one v_perm per statistic and register (half the L1 traffic of unpacked planes)
-                const uint32_t vg = rq[0][k] & 0x00FF00FFu, vg0 = rq[1][k] & 0x00FF00FFu, vg1 = rq[2][k] & 0x00FF00FFu;
-                const uint32_t vr = __builtin_amdgcn_perm(0u, rq[0][k], 0x0C030C01u), vr0 = __builtin_amdgcn_perm(0u, rq[1][k], 0x0C030C01u);
-                const uint32_t vr1 = __builtin_amdgcn_perm(0u, rq[2][k], 0x0C030C01u);
+                uint32_t vg, vg0, vg1, vr, vr0, vr1;
+                if (STAGE) {
+                    vg = st[0][k]; vg0 = st[1][k]; vg1 = st[2][k]; vr = st[3][k]; vr0 = st[4][k]; vr1 = st[5][k];
+                } else {
+                    // unpack: one v_and / one v_perm per statistic and register (half the L1 traffic of unpacked planes)
+                    vg = rq[0][k] & 0x00FF00FFu; vg0 = rq[1][k] & 0x00FF00FFu; vg1 = rq[2][k] & 0x00FF00FFu;
+                    vr = __builtin_amdgcn_perm(0u, rq[0][k], 0x0C030C01u); vr0 = __builtin_amdgcn_perm(0u, rq[1][k], 0x0C030C01u);
+                    vr1 = __builtin_amdgcn_perm(0u, rq[2][k], 0x0C030C01u);
+                }
+                if (SV_COST_ABL & 8) pv[k] += (ug ^ vg) + (ug0 ^ vg0) + (ug1 ^ vg1) + (ur ^ vr) + (ur0 ^ vr0) + (ur1 ^ vr1);
+                else
                 pv[k] += bt_pk2(ug, ug0, ug1, vg, vg0, vg1) + __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, bt_pk2(ur, ur0, ur1, vr, vr0, vr1)) >> 2);
             }
             if (ch + 1 < cn) prefetch(ry, ch + 1);
@@ -418,6 +519,10 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     // tap count is a compile-time constant of the body), the BT costs of row ry + 1 are computed
     // into the other half while they arrive, then the taps are summed, the row sum goes into the
     // thread's private ring and the vertical running sum moves one row down.
+    // The stage runs further ahead: during the trip of row ry the BT costs of row ry + 1 start from registers filled in the
+    // trip before, the statistics of row ry + 2 are read from stage[ry & 1] into those registers afterwards, the dwords of
+    // row ry + 3 (loaded in the trip before) are unpacked into stage[(ry + 1) & 1], whose readers passed the barrier, and the
+    // dwords of row ry + 4 are requested.
     auto run = [&](auto taps_tag) {
         constexpr int TAPS = decltype(taps_tag)::value;
         const int r_begin = max(ys - radius, 0), r_init_end = ys + radius;
@@ -426,8 +531,23 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
         uint32_t* outaddr = sinkp;
 #pragma unroll
         for (int k = 0; k < N; k++) acc[k] = outp[k] = 0;
+        if (STAGE) {
+            stage_load(r_begin);
+            stage_write(r_begin & 1);
+            stage_load(r_begin + 1);
+            stage_write((r_begin + 1) & 1);
+            stage_load(r_begin + 2);
+            __syncthreads();
+            stage_read(r_begin & 1);
+        }
         prefetch(r_begin, 0);
         bt_store(r_begin);
+        if (STAGE) {
+            stage_read((r_begin + 1) & 1);
+            __syncthreads();                 // every lane has row r_begin's statistics in registers: its buffer takes row r_begin + 2
+            stage_write(r_begin & 1);
+            stage_load(r_begin + 3);
+        }
         for (int ry = r_begin; ry <= r_end; ry++) {
             // pix[ry & 1] complete; its previous contents (row ry-2) were consumed before the last
             // barrier.  LDS only: __syncthreads() would also wait for the prefetch in flight (vmcnt(0)).
@@ -443,33 +563,44 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
             const uint32_t* pw = mypix + (ry & 1) * (NCOL * D2);
             if (j < TX) {
 #pragma unroll
-                for (int t = 0; t < TAPS; t++) load_regs<N>(pw + t * 16 * N, v[t]);
+                for (int t = 0; t < ((SV_COST_ABL & 4) ? 1 : TAPS); t++) load_regs<N>(pw + t * 16 * N, v[t]);
             }
             bt_store(ry + 1);   // also after the last row (row clamped, result unused): no vector memory operation of the loop sits behind a branch
+            if (STAGE && !(SV_COST_ABL & 2)) {
+                stage_read(ry & 1);              // row ry + 2 (written in the trip before) -> registers, for the next trip's costs
+                stage_write((ry + 1) & 1);       // row ry + 3 -> the buffer whose contents (row ry + 1) went to registers in the trip before
+                stage_load(ry + 4);
+            }
             if (j < TX) {
                 uint32_t hs[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) hs[k] = 0;
 #pragma unroll
-                for (int t = 0; t < TAPS; t++)
+                for (int t = 0; t < ((SV_COST_ABL & 4) ? 1 : TAPS); t++)
 #pragma unroll
                     for (int k = 0; k < N; k++) hs[k] += v[t][k];  // <= (2 cap + 63) * 15 <= 4755 per half: no carry
-                store_regs<N>(myring + (ry % ringn) * (TX * D2), hs);
+                // the ring holds the last 2r + 1 row sums: the oldest one leaves (it is read first) where the new one goes
+                uint32_t* const slot = myring + (ry % ringn) * (TX * D2);
                 if (ry <= r_init_end) {
                     const uint32_t mult = ry == 0 ? (uint32_t)(radius - ys + 1) : 1u;  // row 0 stands for every row above it
 #pragma unroll
                     for (int k = 0; k < N; k++) acc[k] += hs[k] * mult;
+                } else if (SV_COST_ABL & 16) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) acc[k] = acc[k] + hs[k];
                 } else {
                     uint32_t old[N];
                     load_regs<N>(myring + (max(ry - 2 * radius - 1, 0) % ringn) * (TX * D2), old);
+                    asm volatile("" ::: "memory");   // the store below stays behind this load (same slot when ry > 2r)
 #pragma unroll
                     for (int k = 0; k < N; k++) acc[k] = acc[k] + hs[k] - old[k];
                 }
+                if (!(SV_COST_ABL & 16)) store_regs<N>(slot, hs);
             }
             const int y = ry - radius;
 #pragma unroll
             for (int k = 0; k < N; k++) outp[k] = acc[k] + P2P2;
-            outaddr = (ry >= r_init_end && y >= y0 && colok) ? Cout + (size_t)y * rowN : sinkp;
+            outaddr = (ry >= r_init_end && y >= y0 && colok && !(SV_COST_ABL & 1)) ? Cout + (size_t)y * rowN : sinkp;
         }
         store_regs<N>(outaddr, outp);
         // the bottom `radius` rows repeat the last computed row (costs.cu:279-282), or hold P2
