@@ -152,6 +152,41 @@ __device__ __forceinline__ void store_regs(uint32_t* __restrict__ p, const uint3
     }
 }
 
+// Vector memory operations the compiler does not count (k_cost2's row loop).  hipcc places `s_waitcnt vmcnt(n)` with n the
+// smallest count over every path into the wait, so a loop whose entry and back edge carry different operations in flight waits
+// for more than it needs - in k_cost2 for the C store of the row before, a write round trip per image row.  Issued from
+// inline assembly the operations are invisible to that pass and the waits are written by hand (vm_wait), exact: vmcnt counts
+// the operations issued after the one waited for, in program order.  The destination is an in/out operand so that a slot of
+// a prefetch queue keeps one register for the life of the loop, and vm_wait takes it the same way so that no use of the
+// loaded value moves above the wait.  Stores: the data registers may be written two wait states after the store (s_nop 1).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vm_load_b64(u32x2& dst, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(dst) : "v"(p)); }
+__device__ __forceinline__ void vm_load_b32(uint32_t& dst, const void* p) { asm volatile("global_load_dword %0, %1, off" : "+v"(dst) : "v"(p)); }
+template <int CNT>
+__device__ __forceinline__ void vm_wait(u32x2& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void vm_wait(uint32_t& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void vm_wait(uint32_t& a, uint32_t& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }
+template <int N>
+__device__ __forceinline__ void vm_store_regs(uint32_t* p, const uint32_t (&r)[N]) {
+    static_assert(N >= 1 && N <= 4, "one store instruction");
+    if constexpr (N == 1) {
+        asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(r[0]));
+    } else if constexpr (N == 2) {
+        const u32x2 v = {r[0], r[1]};
+        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v));
+    } else if constexpr (N == 3) {
+        const u32x3 v = {r[0], r[1], r[2]};
+        asm volatile("global_store_dwordx3 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v));
+    } else {
+        const u32x4 v = {r[0], r[1], r[2], r[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage 1: prefilter + Birchfield-Tomasi interval statistics.
 // Result of get_gradient (sgbm_cuda/costs.cu:116-166, clip table :286-292) followed by the
@@ -332,6 +367,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // BT phase: the costs of tile column j for its 2N disparities -> LDS; window phase (j < TX): the
 // 2r+1-tap horizontal sum for output column j from LDS, the last 2r+2 sums in a private LDS ring,
 // the vertical running sum in registers, C out with the 16-byte stores k_agg / k_sweep read back.
+#ifndef SV_COST_DEPTH
+#define SV_COST_DEPTH 2   // image rows the gray cost kernel's loads run ahead of their use (k_cost2, STAGE path)
+#endif
 #ifndef SV_COST_ABL
 #define SV_COST_ABL 0   // diagnostic builds (wrong results): 1 C to the sink, 2 no stage reads / writes, 4 one window tap, 8 no BT arithmetic, 16 no ring
 #endif
@@ -431,11 +469,11 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
 #pragma unroll
         for (int t = 0; t < ITEMS; t++) sv[t] = rowp[sv_src[t]];
     };
-    auto stage_write = [&](int par) {
+    auto stage_write = [&](int par, const uint32_t (&dw)[ITEMS]) {
         uint32_t* const dstb = rs + par * RSBUF;
 #pragma unroll
         for (int t = 0; t < ITEMS; t++) {
-            const uint32_t g = sv[t] & 0x00FF00FFu, r = __builtin_amdgcn_perm(0u, sv[t], 0x0C030C01u);
+            const uint32_t g = dw[t] & 0x00FF00FFu, r = __builtin_amdgcn_perm(0u, dw[t], 0x0C030C01u);
             const int d0 = sv_dst[t], mm = sv_mm[t];
             if (mm >= 0 && mm < SPANW) *reinterpret_cast<uint2*>(dstb + 2 * d0) = make_uint2(g, r);                    // copy gc, entry mm
             if (mm >= 1) *reinterpret_cast<uint2*>(dstb + 2 * (d0 + 2 * SPANW - 1)) = make_uint2(g, r);                 // copy gc + 2, entry mm - 1
@@ -479,7 +517,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     // BT costs of image row ry, summed over the cn colour planes (operands of plane 0 in lrec / rq,
     // prefetched) -> pix[ry & 1]; while a plane is computed the operands of the next plane, or of
     // plane 0 of the next row, are on their way.
-    auto bt_store = [&](int ry) {
+    auto bt_store = [&](int ry, auto&& unpacked) {   // unpacked(): called once the left record is in its six registers
         uint32_t pv[N];
 #pragma unroll
         for (int k = 0; k < N; k++) pv[k] = 0;
@@ -488,6 +526,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
             const uint32_t ug = (lrec.x & 0xFFu) * 0x10001u, ug0 = ((lrec.x >> 8) & 0xFFu) * 0x10001u;
             const uint32_t ug1 = ((lrec.x >> 16) & 0xFFu) * 0x10001u, ur = (lrec.x >> 24) * 0x10001u;
             const uint32_t ur0 = (lrec.y & 0xFFu) * 0x10001u, ur1 = ((lrec.y >> 8) & 0xFFu) * 0x10001u;
+            unpacked();
 #pragma unroll
             for (int k = 0; k < N; k++) {  // raw channel >> 2 (diff_scale, bova_sgm.cu:97); halves cannot carry
                 uint32_t vg, vg0, vg1, vr, vr0, vr1;
@@ -504,7 +543,7 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
                 pv[k] += bt_pk2(ug, ug0, ug1, vg, vg0, vg1) + __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, bt_pk2(ur, ur0, ur1, vr, vr0, vr1)) >> 2);
             }
             if (ch + 1 < cn) prefetch(ry, ch + 1);
-            else prefetch(ry + 1, 0);
+            else if (!STAGE) prefetch(ry + 1, 0);   // (STAGE: the row loop keeps its own queue of left records)
         }
         store_regs<N>(mypix + (ry & 1) * (NCOL * D2), pv);
     };
@@ -531,46 +570,17 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
         uint32_t* outaddr = sinkp;
 #pragma unroll
         for (int k = 0; k < N; k++) acc[k] = outp[k] = 0;
-        if (STAGE) {
-            stage_load(r_begin);
-            stage_write(r_begin & 1);
-            stage_load(r_begin + 1);
-            stage_write((r_begin + 1) & 1);
-            stage_load(r_begin + 2);
-            __syncthreads();
-            stage_read(r_begin & 1);
-        }
-        prefetch(r_begin, 0);
-        bt_store(r_begin);
-        if (STAGE) {
-            stage_read((r_begin + 1) & 1);
-            __syncthreads();                 // every lane has row r_begin's statistics in registers: its buffer takes row r_begin + 2
-            stage_write(r_begin & 1);
-            stage_load(r_begin + 3);
-        }
-        for (int ry = r_begin; ry <= r_end; ry++) {
-            // pix[ry & 1] complete; its previous contents (row ry-2) were consumed before the last
-            // barrier.  LDS only: __syncthreads() would also wait for the prefetch in flight (vmcnt(0)).
-            lds_barrier();
-            // The row finished in the previous trip is stored here, at the top of the next one, and unconditionally (a thread
-            // with nothing to write - warm-up rows, halo columns - stores to its sink slot).  That keeps the vector memory
-            // operations in flight at the loop's entry and at its back edge the same (the prefetch only) and none of them
-            // behind a branch, so the compiler counts them exactly: the wait for the prefetched operands below is vmcnt(1)
-            // and leaves this store in flight.  With the store at the end of the trip behind its condition the wait was
-            // vmcnt(0) and every row paid a write round trip (27.1 -> ... ms per 1024 C2 frames).
-            store_regs<N>(outaddr, outp);
-            uint32_t v[TAPS][N];
+        // window taps of row ry, requested from pix[ry & 1] right after the barrier
+        auto taps_load = [&](int ry, uint32_t (&v)[TAPS][N]) {
             const uint32_t* pw = mypix + (ry & 1) * (NCOL * D2);
             if (j < TX) {
 #pragma unroll
                 for (int t = 0; t < ((SV_COST_ABL & 4) ? 1 : TAPS); t++) load_regs<N>(pw + t * 16 * N, v[t]);
             }
-            bt_store(ry + 1);   // also after the last row (row clamped, result unused): no vector memory operation of the loop sits behind a branch
-            if (STAGE && !(SV_COST_ABL & 2)) {
-                stage_read(ry & 1);              // row ry + 2 (written in the trip before) -> registers, for the next trip's costs
-                stage_write((ry + 1) & 1);       // row ry + 3 -> the buffer whose contents (row ry + 1) went to registers in the trip before
-                stage_load(ry + 4);
-            }
+        };
+        // window phase of row ry: horizontal sum of the taps, ring, vertical running sum; leaves the finished row of C in
+        // outp / outaddr (stored in the NEXT trip)
+        auto window = [&](int ry, const uint32_t (&v)[TAPS][N]) {
             if (j < TX) {
                 uint32_t hs[N];
 #pragma unroll
@@ -601,6 +611,113 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
 #pragma unroll
             for (int k = 0; k < N; k++) outp[k] = acc[k] + P2P2;
             outaddr = (ry >= r_init_end && y >= y0 && colok && !(SV_COST_ABL & 1)) ? Cout + (size_t)y * rowN : sinkp;
+        };
+        if constexpr (STAGE) {
+            // Three vector memory streams per trip - the left record of a row to come, the stage's dwords of a row to come,
+            // the finished row of C - issued from inline assembly in that order, loads DEPTH trips ahead of their use, and
+            // waited for by hand: the wait for a load lets the K * DEPTH - 1 younger operations stay in flight, so a store
+            // has DEPTH trips to be acknowledged before a wait covers it.  (Left to the compiler the waits were vmcnt(1) where
+            // vmcnt(2) would do - the loop's entry and its back edge carried the operations in different orders - and every
+            // row waited out the store of the row before: under the write stream's load that, not arithmetic, set the pace.)
+            constexpr int DEPTH = SV_COST_DEPTH, K = ITEMS + 2;
+            static_assert(ITEMS >= 1 && ITEMS <= 2 && DEPTH >= 1 && DEPTH <= 4 && K * DEPTH - 1 <= 63, "queue shape");
+            stage_load(r_begin);
+            stage_write(r_begin & 1, sv);
+            stage_load(r_begin + 1);
+            stage_write((r_begin + 1) & 1, sv);
+            stage_load(r_begin + 2);
+            __syncthreads();
+            stage_read(r_begin & 1);
+            prefetch(r_begin, 0);
+            bt_store(r_begin, [] {});
+            stage_read((r_begin + 1) & 1);
+            __syncthreads();                 // every lane has row r_begin's statistics in registers: its buffer takes row r_begin + 2
+            stage_write(r_begin & 1, sv);
+            u32x2 lq[DEPTH];                 // left records of rows ry + 1 .. ry + DEPTH (slot = trip mod DEPTH)
+            uint32_t sq[DEPTH][ITEMS];       // stage dwords of rows ry + 3 .. ry + 2 + DEPTH
+            const uint2* const lbase = stat_l + xj;
+            auto q_lrec = [&](u32x2& d, int row) { vm_load_b64(d, lbase + (size_t)min(row, H - 1) * W); };
+            auto q_stage = [&](uint32_t (&d)[ITEMS], int row) {
+                const uint32_t* rowp = rp32 + (size_t)min(row, H - 1) * (WP / 2);
+#pragma unroll
+                for (int t = 0; t < ITEMS; t++) vm_load_b32(d[t], rowp + sv_src[t]);
+            };
+#pragma unroll
+            for (int p = 0; p < DEPTH; p++) {   // the loop is entered with what its back edge carries in flight
+                lq[p] = u32x2{0u, 0u};
+#pragma unroll
+                for (int t = 0; t < ITEMS; t++) sq[p][t] = 0;
+                q_lrec(lq[p], r_begin + 1 + p);
+                q_stage(sq[p], r_begin + 3 + p);
+                vm_store_regs<N>(sinkp, outp);
+            }
+            // Trip of row ry: after the barrier pix[ry & 1] is complete (its previous contents, row ry - 2, were consumed
+            // before the barrier of the trip before) and its taps are requested; the BT costs of row ry + 1 are computed from
+            // registers (left record from the queue, right statistics read from the stage in the trip before) while they
+            // arrive; the stage's buffer of row ry + 2 goes to registers, the dwords of row ry + 3 are unpacked into the
+            // buffer that row ry + 1 left; then the window sums of row ry.
+            auto trip = [&](int ry, auto ptag) {
+                constexpr int p = decltype(ptag)::value;
+                lds_barrier();   // LDS only: __syncthreads() would drain the queues
+                uint32_t v[TAPS][N];
+                taps_load(ry, v);
+#ifdef SV_COST_DRAIN
+                vm_wait<0>(lq[p]);
+#else
+                vm_wait<K * DEPTH - 1>(lq[p]);
+#endif
+                lrec = make_uint2(lq[p].x, lq[p].y);
+                bt_store(ry + 1, [&] { q_lrec(lq[p], ry + 1 + DEPTH); });   // (the slot is free once the record is unpacked)
+                stage_read(ry & 1);
+#ifdef SV_COST_DRAIN
+                if constexpr (ITEMS == 1) vm_wait<0>(sq[p][0]);
+                else vm_wait<0>(sq[p][0], sq[p][1]);
+#else
+                if constexpr (ITEMS == 1) vm_wait<K * DEPTH - ITEMS>(sq[p][0]);
+                else vm_wait<K * DEPTH - ITEMS>(sq[p][0], sq[p][1]);
+#endif
+                stage_write((ry + 1) & 1, sq[p]);
+                q_stage(sq[p], ry + 3 + DEPTH);
+                vm_store_regs<N>(outaddr, outp);   // the row finished in the trip before
+                if (ry <= r_end) window(ry, v);    // (trips past the band's last row: see below)
+            };
+            // Whole rounds of DEPTH trips, one exit at the bottom: a queue slot is then one value that lives in one register
+            // around the loop.  (With an exit after every trip the compiler kept some slots in two registers and copied between
+            // them - copies of a register whose load is still in flight.  tests/test_cost_queue_isa.py checks the listing for
+            // any such copy.)  The up to DEPTH - 1 trips past the last row cost rows clamped to the image, store the last row
+            // of C once more and leave the sums alone.
+            const int rounds = (r_end - r_begin + DEPTH) / DEPTH;
+            for (int it = 0, ry = r_begin; it < rounds; it++, ry += DEPTH) {
+                trip(ry, std::integral_constant<int, 0>{});
+                if constexpr (DEPTH > 1) trip(ry + 1, std::integral_constant<int, 1>{});
+                if constexpr (DEPTH > 2) trip(ry + 2, std::integral_constant<int, 2>{});
+                if constexpr (DEPTH > 3) trip(ry + 3, std::integral_constant<int, 3>{});
+            }
+#pragma unroll
+            for (int p = 0; p < DEPTH; p++) {   // loads still in flight land in registers that stay theirs until here
+                vm_wait<0>(lq[p]);
+#pragma unroll
+                for (int t = 0; t < ITEMS; t++) vm_wait<0>(sq[p][t]);
+            }
+        } else {
+            prefetch(r_begin, 0);
+            bt_store(r_begin, [] {});
+            for (int ry = r_begin; ry <= r_end; ry++) {
+                // pix[ry & 1] complete; its previous contents (row ry-2) were consumed before the last
+                // barrier.  LDS only: __syncthreads() would also wait for the prefetch in flight (vmcnt(0)).
+                lds_barrier();
+                // The row finished in the previous trip is stored here, at the top of the next one, and unconditionally (a thread
+                // with nothing to write - warm-up rows, halo columns - stores to its sink slot).  That keeps the vector memory
+                // operations in flight at the loop's entry and at its back edge the same (the prefetch only) and none of them
+                // behind a branch, so the compiler counts them exactly: the wait for the prefetched operands below is vmcnt(1)
+                // and leaves this store in flight.  With the store at the end of the trip behind its condition the wait was
+                // vmcnt(0) and every row paid a write round trip (27.1 -> 24.0 ms per 1024 C2 frames).
+                store_regs<N>(outaddr, outp);
+                uint32_t v[TAPS][N];
+                taps_load(ry, v);
+                bt_store(ry + 1, [] {});   // also after the last row (row clamped, result unused): no vector memory operation of the loop sits behind a branch
+                window(ry, v);
+            }
         }
         store_regs<N>(outaddr, outp);
         // the bottom `radius` rows repeat the last computed row (costs.cu:279-282), or hold P2
