@@ -1,4 +1,4 @@
-"""Checks a device listing (scratch/isa.sh -> /tmp/sv.s) for the one thing the hand-counted memory queue of k_cost2 cannot survive:
+"""Checks a device listing (hipcc --cuda-device-only -S) for the one thing the hand-counted memory queue of k_cost2 cannot survive:
 an instruction outside the inline assembly that writes a queue register, or a move that reads one (a copy of a register whose load
 may still be in flight).  check_cost_queue.py [listing]; exit status 1 and the offending lines if any."""
 import re, sys
