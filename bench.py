@@ -343,7 +343,9 @@ def main():
             kstats.append({"kernel": nm, "launch_us": round(ms_ * 1e3, 2), "algorithmic_bytes": by,
                            "achieved_gbs": round(by / (ms_ * 1e-3) / 1e9, 1), "frac": round(by / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            "traffic": tr, "hbm_actual_gbs": round(tr / (ms_ * 1e-3) / 1e9, 1) if tr else None})
-        cost_name = "svk::k_cost2<%d, %d, 1>" % (D // 32, 1024 if (B >= 8 and D <= 128) else 512)
+        # the kernel launch_cost2 picks for a gray batch with 7x7 blocks: D > 128 runs as disparity parts of the D <= 128 kernel
+        n32 = D // 32
+        cost_name = "svk::k_cost2<%d, %d, 1>" % ((n32 if n32 <= 4 else (n32 + 1) // 2, 1024) if B >= 8 else (n32, 512))
         cost_bytes = (V + 2 * W * H) * B
         cost_tr = traffic_by_kernel.get(cost_name)
         kstats.append({"kernel": cost_name + " (+ k_cost_col0; stage time)", "launch_us": round(stage_ms["cost"] * 1e3, 2),

@@ -404,8 +404,9 @@ int run_paths_fanout(sv_ctx* c, int f_start, int nb, int chunk) {
     return SV_OK;
 }
 
+// dpart0, nparts: the launch costs disparities dpart0 .. dpart0 + 32 N nparts - 1 of the volume's D (k_cost2: disparity parts)
 template <int N, int CN, int NT = 512>
-int launch_cost2_n(sv_ctx* c, int nb) {
+int launch_cost2_n(sv_ctx* c, int nb, int dpart0 = 0, int nparts = 1, bool col0 = true) {
     // CN = colour planes in the cost: 1 (gray) or 3 (SV_FLAG_COST_RGB)
     constexpr int NCOL = NT / 16;
     const sv_params& p = c->prm;
@@ -416,13 +417,13 @@ int launch_cost2_n(sv_ctx* c, int nb) {
         // BT costs for 58 instead of 26 output columns: 27.9 -> 27.2 ms per 1024 frames at C2.  Only where the
         // tile fits the 160 KB of LDS (D <= 128 with blocks up to 7x7) and the launch has enough tiles to go round.
         if (nb >= 8 && 64 - 2 * r >= 16 && svk::cost_lds_bytes<N, 1024, CN>(r) <= 160 * 1024 && c->debug_mode != 4 && !getenv("SV_COST_NT512"))
-            return launch_cost2_n<N, CN, 1024>(c, nb);
+            return launch_cost2_n<N, CN, 1024>(c, nb, dpart0, nparts, col0);
     }
     if (TX < 1) return fail(c, SV_ERR_UNSUPPORTED, "block size %d leaves no output column in a %d-column tile", p.block_size, NCOL);
     const size_t lds = svk::cost_lds_bytes<N, NT, CN>(r);
     if (lds > 160 * 1024) {
         // D >= 224 with blocks from 11 x 11: the ring of a 32-column tile passes the 160 KB.  24 tile columns fit.
-        if constexpr (NT == 512 && N >= 7) return launch_cost2_n<N, CN, 384>(c, nb);
+        if constexpr (NT == 512 && N >= 7) return launch_cost2_n<N, CN, 384>(c, nb, dpart0, nparts, col0);
         return fail(c, SV_ERR_UNSUPPORTED, "cost kernel tile of %zu bytes exceeds the 160 KB of LDS", lds);
     }
     bool* attr_set = c->attr_cost2[CN == 3][NT == 512 ? 0 : (NT == 384 ? 1 : 2)];  // per context: the attribute is per device
@@ -439,20 +440,32 @@ int launch_cost2_n(sv_ctx* c, int nb) {
     const int yband = (H + bands - 1) / bands;
     const int nbands = (H + yband - 1) / yband;
     const bool by_xcd = nb >= 8;  // below that the frame -> XCD order would leave XCDs idle
-    const size_t n_wg = (size_t)ntx * nbands * (by_xcd ? (nb + 7) / 8 * 8 : nb);
+    const size_t n_wg = (size_t)ntx * nbands * nparts * (by_xcd ? (nb + 7) / 8 * 8 : nb);
     if (n_wg > 0x7FFFFFFFu) return fail(c, SV_ERR_UNSUPPORTED, "batch too large for one cost launch");
     if (int rc = ensure(c, c->cost_sink, (size_t)svk::COST_SINK_SLOTS * NT * N * 4)) return rc;
     hipLaunchKernelGGL((svk::k_cost2<N, NT, CN>), dim3((unsigned)n_wg), dim3(NT), lds, c->stream,
                        (const uint2*)c->stat_l.p, (const uint16_t*)c->stat_r.p, (uint32_t*)c->C.p, W, H, WP, r, yband,
                        (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_TAIL_P2) ? 1 : 0, ntx, nbands, by_xcd ? nb : -nb,
-                       geo_col0(W, p), W1, p.min_disparity, (uint32_t*)c->cost_sink.p);
-    if (H > 1)
+                       geo_col0(W, p), W1, p.min_disparity, D / 2, dpart0, nparts, (uint32_t*)c->cost_sink.p);
+    if (H > 1 && col0)
         hipLaunchKernelGGL(svk::k_cost_col0, dim3(H - 1, nb), dim3(128), 0, c->stream, (uint32_t*)c->C.p, W1, H, D / 2,
                            (uint32_t)p.P2 * 0x10001u, (p.flags & SV_FLAG_C_COL0_P2) ? 1 : 0);
     return SV_OK;
 }
 int launch_cost2(sv_ctx* c, int nb) {
     const bool rgb = (c->prm.flags & SV_FLAG_COST_RGB) != 0;
+    // D > 128, gray, large batches: two disparity parts of at most 128 on the D <= 128 kernel's 64-column tiles and LDS stage
+    // (C4, 98 frames: 39.6 ms as one N = 8 part, two waves per SIMD on 32-column tiles)
+    const int n32 = c->prm.num_disparities / 32, r = c->prm.block_size / 2;
+    if (!rgb && n32 > 4 && nb >= 8 && 64 - 2 * r >= 16 && svk::cost_lds_bytes<4, 1024, 1>(r) <= 160 * 1024 && c->debug_mode != 4 &&
+        !getenv("SV_COST_NOPARTS")) {
+        switch (n32) {
+            case 5: if (int rc = launch_cost2_n<3, 1>(c, nb, 0, 1, false)) return rc; return launch_cost2_n<2, 1>(c, nb, 96, 1);
+            case 6: return launch_cost2_n<3, 1>(c, nb, 0, 2);
+            case 7: if (int rc = launch_cost2_n<4, 1>(c, nb, 0, 1, false)) return rc; return launch_cost2_n<3, 1>(c, nb, 128, 1);
+            default: return launch_cost2_n<4, 1>(c, nb, 0, 2);
+        }
+    }
     switch (c->prm.num_disparities / 32) {
         case 1: return rgb ? launch_cost2_n<1, 3>(c, nb) : launch_cost2_n<1, 1>(c, nb);
         case 2: return rgb ? launch_cost2_n<2, 3>(c, nb) : launch_cost2_n<2, 1>(c, nb);

@@ -402,7 +402,7 @@ template <int N, int NT, int CN>
 __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
                                                uint32_t* __restrict__ C, int W, int H, int WP, int radius, int yband,
                                                uint32_t P2P2, int tail_p2, int ntx, int nbands, int nframes, int col0, int W1,
-                                               int min_disp, uint32_t* __restrict__ sink) {
+                                               int min_disp, int cs, int dpart0, int nparts, uint32_t* __restrict__ sink) {
     constexpr int cn = CN;  // colour planes summed into the cost (1 = gray, 3 = RGB)
     constexpr bool STAGE = cost_stage<N, CN>();   // right statistics through the LDS stage (cost_stage_spanw); the colour cost and D > 128 keep the direct loads
     extern __shared__ __align__(16) uint32_t c2_lds[];
@@ -419,17 +419,23 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
     // picks the frame within a group of 8 and all column tiles of a frame (whose right-image reads
     // overlap by D + 2r columns) share one XCD's L2.
     // Fewer than 8 frames (nframes < 0 on entry: plain order): a frame's tiles spread over all XCDs.
-    const int per_frame = ntx * nbands;
+    // Disparity parts: a workgroup costs 32 N disparities, the volume may hold more (cs = dwords of a pixel in C): part p of
+    // the launch covers disparities dpart0 + 32 N p onwards and writes that slice of every pixel's line.  D = 256 runs as
+    // two parts of N = 4 on the 64-column tiles and the LDS stage of the D <= 128 kernel (its own N = 8 form has two waves
+    // per SIMD and 32-column tiles); the parts of a tile are neighbours in the grid (same frame, same XCD).
+    const int per_frame = ntx * nbands * nparts;
     const int wg = blockIdx.x;
     const bool by_xcd = nframes > 0;
     const int fr = by_xcd ? (wg / 8 / per_frame) * 8 + (wg & 7) : wg / per_frame;
-    const int tb = by_xcd ? (wg / 8) % per_frame : wg % per_frame;
+    const int tbp = by_xcd ? (wg / 8) % per_frame : wg % per_frame;
+    const int tb = tbp / nparts, doff = dpart0 + (tbp % nparts) * (32 * N);
+    min_disp += doff;   // from here on: the shift between a cost index of this part and the right image's column
     if (fr >= (by_xcd ? nframes : -nframes)) return;
     const int xl0 = (tb % ntx) * TX;
     const int y0 = (tb / ntx) * yband, y1 = min(y0 + yband, H);
     stat_l += (size_t)fr * cn * W * H;
     const uint32_t* rp32 = reinterpret_cast<const uint32_t*>(rp + (size_t)fr * cn * 6 * H * WP);
-    C += (size_t)fr * H * W1 * D2;
+    C += (size_t)fr * H * W1 * cs + doff / 2;
     // BT item of this thread: tile column j (clamped into the computable band), disparities 2N*q ..
     const int xj = min(max(xl0 - radius + j, 0), W1 - 1) + col0;
     const int e = (W - 1 - xj) + min_disp + 2 * N * q;  // reversed index of x - d - min_disp for the first disparity
@@ -550,9 +556,9 @@ __global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, 
 
     const int ylast = H - 1 - radius;
     const int ys = min(y0, ylast);
-    uint32_t* Cout = C + (size_t)min(xl, W1 - 1) * D2 + q * N;
+    uint32_t* Cout = C + (size_t)min(xl, W1 - 1) * cs + q * N;
     uint32_t* const sinkp = sink + ((size_t)(blockIdx.x & (COST_SINK_SLOTS - 1)) * NT + tid) * N;   // shared by workgroups: never read
-    const size_t rowN = (size_t)W1 * D2;
+    const size_t rowN = (size_t)W1 * cs;
     // The rows of the band as a software pipeline, one LDS-only barrier per image row: after the
     // barrier the window taps of row ry are requested from pix[ry & 1] (all of them in flight: the
     // tap count is a compile-time constant of the body), the BT costs of row ry + 1 are computed
