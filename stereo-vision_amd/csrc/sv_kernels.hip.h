@@ -170,20 +170,23 @@ template <int CNT>
 __device__ __forceinline__ void vm_wait(uint32_t& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(CNT)); }
 template <int CNT>
 __device__ __forceinline__ void vm_wait(uint32_t& a, uint32_t& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }
+#ifndef SV_COST_ST_MOD
+#define SV_COST_ST_MOD ""   // cache policy bits of the C store (experiments: " nt", " sc1", " sc0 sc1")
+#endif
 template <int N>
 __device__ __forceinline__ void vm_store_regs(uint32_t* p, const uint32_t (&r)[N]) {
     static_assert(N >= 1 && N <= 4, "one store instruction");
     if constexpr (N == 1) {
-        asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(r[0]));
+        asm volatile("global_store_dword %0, %1, off" SV_COST_ST_MOD "\n\ts_nop 1" ::"v"(p), "v"(r[0]));
     } else if constexpr (N == 2) {
         const u32x2 v = {r[0], r[1]};
-        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v));
+        asm volatile("global_store_dwordx2 %0, %1, off" SV_COST_ST_MOD "\n\ts_nop 1" ::"v"(p), "v"(v));
     } else if constexpr (N == 3) {
         const u32x3 v = {r[0], r[1], r[2]};
-        asm volatile("global_store_dwordx3 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v));
+        asm volatile("global_store_dwordx3 %0, %1, off" SV_COST_ST_MOD "\n\ts_nop 1" ::"v"(p), "v"(v));
     } else {
         const u32x4 v = {r[0], r[1], r[2], r[3]};
-        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v));
+        asm volatile("global_store_dwordx4 %0, %1, off" SV_COST_ST_MOD "\n\ts_nop 1" ::"v"(p), "v"(v));
     }
 }
 
