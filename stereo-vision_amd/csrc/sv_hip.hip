@@ -869,7 +869,12 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         const int sw_pipes = sweep_pipes(c, sweep_cw_for(c, nb));
         const int sw_auto = (D > 128 || c->sweep_cw) ? sw_pipes : (5 * sweep_pipes(c, 7) + 7) / 8;
         const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : sw_auto;
-        const bool sweep_ok = !c->debug && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= sw_min);
+        // The sweeps take min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1) with the packed binary16 three-input minimum (sv_sweep.hip.h,
+        // pk_min3), which orders u16 values below 0x7C00 like integers: every L (<= the largest cost) plus P1 has to stay
+        // there.  sv_check_params allows costs up to 32767: the parameter sets in between take the per-path kernels.
+        const long cmax = (long)((p.flags & SV_FLAG_COST_RGB) ? 3 : 1) * (2 * p.pre_filter_cap + 63) * p.block_size * p.block_size + p.P2;
+        const bool sweep_f16_ok = cmax + p.P1 <= 0x7BFF;
+        const bool sweep_ok = !c->debug && c->sweep_mode >= 0 && (c->sweep_mode > 0 || nb >= sw_min) && sweep_f16_ok;
         const bool sw1 = sweep_ok && (p.path_mask & 0x0Fu) == 0x0Fu;
         const bool sw2 = sw1 && (p.path_mask & 0xF0u) == 0xF0u;
         uint32_t rest = p.path_mask;

@@ -99,27 +99,44 @@ __host__ __device__ constexpr size_t sweep_lds_bytes() {
 //   L = C + min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1, dd) - dd  =  C - max(dd - a, 0).
 // The neighbour lanes' registers arrive through DPP row shifts folded into an OR (v_or_b32_dpp with
 // bound_ctrl: the lane with no neighbour reads 0) with a per-lane constant: "no such disparity" =
-// 0x7FFF7FFF in lane 0 (big15: lane 15) of the row, 0 elsewhere.  One instruction per shift, no landing
+// SW_BIG in lane 0 (big15: lane 15) of the row, 0 elsewhere.  One instruction per shift, no landing
 // register to initialise or keep.
+// Packed three-input minimum of u16 pairs: v_pk_minimum3_f16 (new on gfx950).  Non-negative finite binary16 patterns
+// (0 .. 0x7BFF) order like the integers they spell, denormals included under the kernel's default f16 denormal mode, and a minimum
+// returns one of its inputs bit for bit; scratch/ubench/pkmin3.hip checks every pair of [0, 0x7C00)^2 on the GPU and times it
+// (one issue slot, like v_pk_min_u16).  The host runs the sweeps only where every value that meets one of these stays below
+// 0x7C00 (sweep_f16_ok: largest cost + P1 <= 0x7BFF); the thin slice of parameter sets above that takes the per-path kernels.
+constexpr uint32_t SW_BIG = 0x7BFF7BFFu;   // "no such disparity": never below a real value, and still a finite binary16
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef SV_SWEEP_U16MIN
+    return pk_min(pk_min(a, b), c);
+#else
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
 template <int N>
 __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&r)[N], uint32_t dd, uint32_t P1P1,
                                            uint32_t (&L)[N], uint32_t& mn_out, uint32_t big0, uint32_t big15) {
-    const uint32_t prevHi = big0 | dpp<DPP_ROW_SHR1>(0u, r[N - 1]);
-    const uint32_t nextLo = big15 | dpp<DPP_ROW_SHL1>(0u, r[0]);
+    // P1 goes onto the previous L BEFORE the neighbours are fetched, so that min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1) is one
+    // three-input minimum per register: 4 instructions per register (add, min3, saturating subtract, subtract) instead of 6.
+    // Plain 32-bit add / subtract where no half can carry or borrow: every L <= 0x7BFF - P1; C >= P2 >= max(dd - t, 0).
+    uint32_t rp[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) rp[k] = r[k] + P1P1;
+    const uint32_t prevHi = big0 | dpp<DPP_ROW_SHR1>(0u, rp[N - 1]);
+    const uint32_t nextLo = big15 | dpp<DPP_ROW_SHL1>(0u, rp[0]);
     uint32_t m[N + 1];
-    m[0] = __builtin_amdgcn_alignbit(r[0], prevHi, 16);
+    m[0] = __builtin_amdgcn_alignbit(rp[0], prevHi, 16);
 #pragma unroll
-    for (int k = 1; k < N; k++) m[k] = __builtin_amdgcn_alignbit(r[k], r[k - 1], 16);
-    m[N] = __builtin_amdgcn_alignbit(nextLo, r[N - 1], 16);
-    uint32_t mn = 0xFFFFFFFFu;
+    for (int k = 1; k < N; k++) m[k] = __builtin_amdgcn_alignbit(rp[k], rp[k - 1], 16);
+    m[N] = __builtin_amdgcn_alignbit(nextLo, rp[N - 1], 16);
 #pragma unroll
-    for (int k = 0; k < N; k++) {
-        // plain 32-bit add / subtract where no half can carry or borrow (cheaper to issue than the packed forms):
-        // every L <= 32767 and sv_check_params keeps 32767 + P1 <= 65535; C >= P2 >= max(dd - t, 0)
-        const uint32_t t = pk_min(pk_min(m[k], m[k + 1]) + P1P1, r[k]);
-        L[k] = c[k] - pk_sub_sat(dd, t);
-        mn = pk_min(mn, L[k]);
-    }
+    for (int k = 0; k < N; k++) L[k] = c[k] - pk_sub_sat(dd, pk_min3(m[k], m[k + 1], r[k]));
+    uint32_t mn = (N & 1) ? L[N - 1] : pk_min(L[N - 2], L[N - 1]);
+#pragma unroll
+    for (int k = 0; k + 1 < N - 1; k += 2) mn = pk_min3(mn, L[k], L[k + 1]);
     mn_out = mn;  // the minima of the even and of the odd disparities of this lane; sweep_lane_min joins the halves
 }
 // the four paths' lane minima, in both halves of the word; together, so that the four two-instruction chains interleave
@@ -228,7 +245,7 @@ __global__ __launch_bounds__((CW + 1) * 64) void k_sweep(SweepArgs a) {
     uint32_t sp[N];   // sweep 2: finished S of the previous step's pixel (goes to the service wave's slot during this step)
 #pragma unroll
     for (int k = 0; k < N; k++) sp[k] = 0;
-    const uint32_t big0 = q == 0 ? 0x7FFF7FFFu : 0u, big15 = q == 15 ? 0x7FFF7FFFu : 0u;  // see sweep_path
+    const uint32_t big0 = q == 0 ? SW_BIG : 0u, big15 = q == 15 ? SW_BIG : 0u;  // see sweep_path
     uint32_t cb[SW_DEPTH][N], sb[SW_DEPTH][N], offq[SW_DEPTH];
     const uint32_t frame_px = (uint32_t)H * a.W;
     bool actq[SW_DEPTH];

@@ -279,3 +279,24 @@ def test_sweep_timeout_falls_back_to_per_path_kernels(gpu):
     for i in range(nb):
         assert np.array_equal(outs[i], refs[i % nd]), "frame %d differs" % i
     m.close()
+
+
+@pytest.mark.parametrize("P2,sweeps", [(29900, 2), (30100, 0)])
+def test_sweep_value_range_gate(gpu, P2, sweeps):
+    """The sweeps order their u16 values with the packed binary16 three-input minimum, exact below 0x7C00: with 3x3 blocks,
+    cap 63 and P1 = 100 the largest cost + P1 is 31 701 at P2 = 29 900 (the sweeps run, every L within 2000 of the limit) and
+    31 901 at P2 = 30 100 (sv_check_params still accepts it; the per-path kernels take it)."""
+    W, H, D = 170, 66, 64
+    rng = np.random.default_rng(5 + P2)
+    left = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    right = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    ph, po = _params(D, 8, block_size=3, pre_filter_cap=63, P1=100, P2=P2)
+    ref, st = svref.sgbm(left, right, po, stages=("C", "mins"))
+    assert int(st["C"].max()) + 100 > 0x7800, "the costs should sit at the top of the range"
+    m = svhip.Matcher(W, H, ph)
+    m.set_debug(3)
+    got = m.compute_gray(left, right)
+    assert m.last_aggregation()[1] == sweeps
+    assert np.array_equal(m.debug_plane(2)[:, D:], st["mins"][:, D:]), "minS differs"
+    assert np.array_equal(got, ref)
+    m.close()
