@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1536, help="stereo pairs per step per GPU (C2: 1536 pairs = 213 GB of the 288 GB of HBM; every workgroup pipeline then streams 48 frames and the fill/drain of the band pipeline is 3.4 %% of a launch: 5 %% at 1024, 10 %% at 512)")
+    ap.add_argument("--batch", type=int, default=None, help="(default 1536; c4: 112) stereo pairs per step per GPU (C2: 1536 pairs = 213 GB of the 288 GB of HBM; every workgroup pipeline then streams 48 frames and the fill/drain of the band pipeline is 3.4 %% of a launch: 5 %% at 1024, 10 %% at 512)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -198,7 +198,9 @@ def main():
     from svhip import synth
 
     W, H, D, paths = CONFIGS[args.config]
-    B = args.batch if args.config != "c4" else min(args.batch, 98)  # C4: 1.84 GB of volumes per pair (98 pairs = 180 GB = 7 pipelines x 14 frames)
+    # C4: 1.84 GB of volumes per pair: 112 pairs = 206 GB = 7 pipelines x 16 frames (a pipeline's block of volumes has to stay
+    # below 16 GiB for the sweeps' 32-bit offsets: 18 frames per pipeline would split the launch)
+    B = args.batch if args.batch else (112 if args.config == "c4" else 1536)
     params = svhip.default_params(D, paths)  # SAD 7, P1 8*49, P2 32*49, cap 63, uniq 15, LR check on
     n_distinct = min(B, 64)   # 64 distinct pairs per stream, looped
     seed0 = 202 if world == 1 else 500 + 64 * rank

@@ -3,7 +3,7 @@
 # kernel stats + FETCH/WRITE PMC for C2 (B=1536), C4 (B=98), C3 (B=128); SQ counters for C2 and C4; throughput vs batch
 L=${1:-d}
 rm -f profiles/r03_traffic.json
-for spec in "c2 1536" "c4 98" "c3 128"; do
+for spec in "c2 1536" "c4 112" "c3 128"; do
   set -- $spec
   scratch/prof_r03.sh r03_${L}_$1 $1 $2 > gpurun_out/r03_${L}_$1.log 2>&1 || { echo "profile $1 failed"; tail -5 gpurun_out/r03_${L}_$1.log; exit 1; }
   rm -rf gpurun_out/r03_${L}_$1/stats gpurun_out/r03_${L}_$1/fetch gpurun_out/r03_${L}_$1/write

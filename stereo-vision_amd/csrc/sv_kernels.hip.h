@@ -370,6 +370,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // BT phase: the costs of tile column j for its 2N disparities -> LDS; window phase (j < TX): the
 // 2r+1-tap horizontal sum for output column j from LDS, the last 2r+2 sums in a private LDS ring,
 // the vertical running sum in registers, C out with the 16-byte stores k_agg / k_sweep read back.
+#ifndef SV_COST_KATTR
+#define SV_COST_KATTR   // experiments: extra attributes of k_cost2, e.g. __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 #ifndef SV_COST_DEPTH
 #define SV_COST_DEPTH 2   // image rows the gray cost kernel's loads run ahead of their use (k_cost2, STAGE path)
 #endif
@@ -402,7 +405,7 @@ __host__ __device__ constexpr size_t cost_lds_bytes(int radius) {
     return ((size_t)(2 * NCOL + (2 * radius + 1) * TX) * (16 * N) + (cost_stage<N, CN>() ? (size_t)2 * 24 * cost_stage_spanw<N, NT>() : 0)) * 4;
 }
 template <int N, int NT, int CN>
-__global__ __launch_bounds__(NT) void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
+__global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restrict__ stat_l, const uint16_t* __restrict__ rp,
                                                uint32_t* __restrict__ C, int W, int H, int WP, int radius, int yband,
                                                uint32_t P2P2, int tail_p2, int ntx, int nbands, int nframes, int col0, int W1,
                                                int min_disp, int cs, int dpart0, int nparts, uint32_t* __restrict__ sink) {
