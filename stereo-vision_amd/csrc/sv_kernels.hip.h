@@ -373,6 +373,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef SV_COST_KATTR
 #define SV_COST_KATTR   // experiments: extra attributes of k_cost2, e.g. __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
+#ifndef SV_COST_TAPS_EARLY
+#define SV_COST_TAPS_EARLY 15   // window taps requested before the BT costs of the next row (the rest after them: fewer registers live across the costs)
+#endif
 #ifndef SV_COST_DEPTH
 #define SV_COST_DEPTH 2   // image rows the gray cost kernel's loads run ahead of their use (k_cost2, STAGE path)
 #endif
@@ -583,11 +586,12 @@ __global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restr
 #pragma unroll
         for (int k = 0; k < N; k++) acc[k] = outp[k] = 0;
         // window taps of row ry, requested from pix[ry & 1] right after the barrier
-        auto taps_load = [&](int ry, uint32_t (&v)[TAPS][N]) {
+        auto taps_load = [&](int ry, uint32_t (&v)[TAPS][N], int t0 = 0, int t1 = 99) {
             const uint32_t* pw = mypix + (ry & 1) * (NCOL * D2);
             if (j < TX) {
 #pragma unroll
-                for (int t = 0; t < ((SV_COST_ABL & 4) ? 1 : TAPS); t++) load_regs<N>(pw + t * 16 * N, v[t]);
+                for (int t = 0; t < ((SV_COST_ABL & 4) ? 1 : TAPS); t++)
+                    if (t >= t0 && t < t1) load_regs<N>(pw + t * 16 * N, v[t]);
             }
         };
         // window phase of row ry: horizontal sum of the taps, ring, vertical running sum; leaves the finished row of C in
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restr
                 constexpr int p = decltype(ptag)::value;
                 lds_barrier();   // LDS only: __syncthreads() would drain the queues
                 uint32_t v[TAPS][N];
-                taps_load(ry, v);
+                taps_load(ry, v, 0, SV_COST_TAPS_EARLY);
 #ifdef SV_COST_DRAIN
                 vm_wait<0>(lq[p]);
 #else
@@ -680,6 +684,7 @@ __global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restr
 #endif
                 lrec = make_uint2(lq[p].x, lq[p].y);
                 bt_store(ry + 1, [&] { q_lrec(lq[p], ry + 1 + DEPTH); });   // (the slot is free once the record is unpacked)
+                taps_load(ry, v, SV_COST_TAPS_EARLY, TAPS);
                 stage_read(ry & 1);
 #ifdef SV_COST_DRAIN
                 if constexpr (ITEMS == 1) vm_wait<0>(sq[p][0]);
