@@ -672,9 +672,15 @@ __global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restr
             // registers (left record from the queue, right statistics read from the stage in the trip before) while they
             // arrive; the stage's buffer of row ry + 2 goes to registers, the dwords of row ry + 3 are unpacked into the
             // buffer that row ry + 1 left; then the window sums of row ry.
+#ifdef SV_COST_ST_SPREAD
+            const bool st_early = ((tid >> 6) & 1) != 0;
+#endif
             auto trip = [&](int ry, auto ptag) {
                 constexpr int p = decltype(ptag)::value;
                 lds_barrier();   // LDS only: __syncthreads() would drain the queues
+#ifdef SV_COST_ST_SPREAD
+                if (st_early) vm_store_regs<N>(outaddr, outp);   // experiment: half of the waves store at the top of the trip
+#endif
                 uint32_t v[TAPS][N];
                 taps_load(ry, v, 0, SV_COST_TAPS_EARLY);
 #ifdef SV_COST_DRAIN
@@ -695,6 +701,9 @@ __global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restr
 #endif
                 stage_write((ry + 1) & 1, sq[p]);
                 q_stage(sq[p], ry + 3 + DEPTH);
+#ifdef SV_COST_ST_SPREAD
+                if (!st_early)
+#endif
                 vm_store_regs<N>(outaddr, outp);   // the row finished in the trip before
                 if (ry <= r_end) window(ry, v);    // (trips past the band's last row: see below)
             };
