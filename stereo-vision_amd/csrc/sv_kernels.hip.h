@@ -373,6 +373,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef SV_COST_KATTR
 #define SV_COST_KATTR   // experiments: extra attributes of k_cost2, e.g. __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
+#ifndef SV_COST_ST_SPREAD
+#define SV_COST_ST_SPREAD 1   // the odd waves of a workgroup store their finished row of C at the top of a trip, the even ones at its end: the
+                              // workgroup's 15 KB do not reach the L1 in one burst (20.9 -> 20.6 ms per 1024 C2 frames; same wait counts,
+                              // the trip's three operations are the same cycle S, L, V entered at another point)
+#endif
 #ifndef SV_COST_TAPS_EARLY
 #define SV_COST_TAPS_EARLY 15   // window taps requested before the BT costs of the next row (the rest after them: fewer registers live across the costs)
 #endif
@@ -672,14 +677,14 @@ __global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restr
             // registers (left record from the queue, right statistics read from the stage in the trip before) while they
             // arrive; the stage's buffer of row ry + 2 goes to registers, the dwords of row ry + 3 are unpacked into the
             // buffer that row ry + 1 left; then the window sums of row ry.
-#ifdef SV_COST_ST_SPREAD
+#if SV_COST_ST_SPREAD
             const bool st_early = ((tid >> 6) & 1) != 0;
 #endif
             auto trip = [&](int ry, auto ptag) {
                 constexpr int p = decltype(ptag)::value;
                 lds_barrier();   // LDS only: __syncthreads() would drain the queues
-#ifdef SV_COST_ST_SPREAD
-                if (st_early) vm_store_regs<N>(outaddr, outp);   // experiment: half of the waves store at the top of the trip
+#if SV_COST_ST_SPREAD
+                if (st_early) vm_store_regs<N>(outaddr, outp);   // (SV_COST_ST_SPREAD)
 #endif
                 uint32_t v[TAPS][N];
                 taps_load(ry, v, 0, SV_COST_TAPS_EARLY);
@@ -701,7 +706,7 @@ __global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restr
 #endif
                 stage_write((ry + 1) & 1, sq[p]);
                 q_stage(sq[p], ry + 3 + DEPTH);
-#ifdef SV_COST_ST_SPREAD
+#if SV_COST_ST_SPREAD
                 if (!st_early)
 #endif
                 vm_store_regs<N>(outaddr, outp);   // the row finished in the trip before
