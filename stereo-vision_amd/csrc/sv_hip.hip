@@ -867,7 +867,9 @@ int run_sgm(sv_ctx* c, const uint8_t* left, const uint8_t* right, int16_t* disp1
         // (with the 8-wave form chosen for small launches: from 5/8 of its pipelines, 18 frames there: 16 frames 2960 vs
         // 3090 frames/s for the per-path kernels, 20 frames 3540 vs 3020; scratch/perf_thresh.py)
         const int sw_pipes = sweep_pipes(c, sweep_cw_for(c, nb));
-        const int sw_auto = (D > 128 || c->sweep_cw) ? sw_pipes : (5 * sweep_pipes(c, 7) + 7) / 8;
+        // (round 3, after the sweeps lost a fifth of their instructions: from half of the 8-wave pipelines, 14 frames: 3630 vs 3460
+        // frames/s, 16 frames 3810 vs 3530; 12 frames 3120 vs 3410; scratch/perf_thresh2.py)
+        const int sw_auto = (D > 128 || c->sweep_cw) ? sw_pipes : (sweep_pipes(c, 7) + 1) / 2;
         const int sw_min = c->sweep_min_batch > 0 ? c->sweep_min_batch : sw_auto;
         // The sweeps take min(Lp(d), Lp(d-1) + P1, Lp(d+1) + P1) with the packed binary16 three-input minimum (sv_sweep.hip.h,
         // pk_min3), which orders u16 values below 0x7C00 like integers: every L (<= the largest cost) plus P1 has to stay
