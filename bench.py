@@ -382,7 +382,9 @@ def main():
                          "hbm_actual_gbs": dom["hbm_actual_gbs"],
                          "hbm_actual_frac": round(dom["hbm_actual_gbs"] / HBM_PEAK_GBS, 4) if dom["hbm_actual_gbs"] else None,
                          "traffic_source": {"file": traffic_file, "kernel_sources_sha": traffic_sha, "this_run_sha": source_sha()},
-                         "limiter": "VALU issue (SQ counters, DESIGN.md section 4); the HBM fraction is what the north star asks for",
+                         "limiter": "VALU issue and HBM together (DESIGN.md section 4); the HBM fraction is what the north star asks for",
+                         # what a load-only kernel with this kernel's streams reaches on an MI355X (recorded, not measured in this run)
+                         "pattern_ceiling_gbs": {"read_C_read_S": 6020, "read_C_write_S": 5680, "source": "profiles/r03_f_access_pattern_ubench.txt"},
                          "per_path_model_gbs": round(per_path_gbs, 1),
                          "hbm_copy_gbs": copy_gbs, "kernels": kstats},
         }
