@@ -18,3 +18,11 @@ for i in range(3):
     m.compute_gray_batch_dev(nb,lt,rt,out)
     m.filter_wls_dev(nb,out,gt,o2,vis,v2)
 torch.cuda.synchronize()
+reps = 10
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(reps):
+    m.filter_wls_dev(nb, out, gt, o2, vis, v2)
+e1.record(); torch.cuda.synchronize()
+print("WLS (16-bit map + vis image) over %d frames: %.3f ms per call, %.2f us per frame%s" % (nb, e0.elapsed_time(e1) / reps, e0.elapsed_time(e1) / reps / nb * 1e3,
+      "  [64-column tiles]" if os.environ.get("SV_FGS_TC64") else ""))

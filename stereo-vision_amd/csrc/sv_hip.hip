@@ -799,7 +799,7 @@ int wls_dev(sv_ctx* c, int nf, const int16_t* d16, const uint8_t* vis, const uin
         if ((long)hgrid.x * hgrid.y <= 4L * c->n_cu)
             hipLaunchKernelGGL(svk::k_fgs_hpass, hgrid, dim3(64), 0, c->stream, cur, wh, tmp, rw, rh, K, lam);
         else
-            hipLaunchKernelGGL(svk::k_fgs_hpass_tiles, hgrid, dim3(64), 0, c->stream, cur, wh, tmp, rw, rh, K, lam);
+            hipLaunchKernelGGL(svk::k_fgs_hpass_tiles<32>, hgrid, dim3(64), 0, c->stream, cur, wh, tmp, rw, rh, K, lam);
         hipLaunchKernelGGL(svk::k_fgs_vpass, dim3((rw + 63) / 64, nimg), dim3(64), 0, c->stream, cur, wv, tmp, rw, rh, K, lam);
         lam *= 0.25f;
     }

@@ -1772,40 +1772,49 @@ __global__ __launch_bounds__(64) void k_fgs_hpass(float* __restrict__ cur, const
 // other waves of the CU covering its load / solve / store phases.  Inside a tile the lane moves FGS_R samples at a
 // time between LDS and registers.  Two tiles of LDS per wave (the super-diagonal takes the weights' place).
 constexpr int FGS_R = 16;
-// 64x64 tile <-> global, one row per wave-load (256 contiguous bytes), 8 rows in flight.  Rows past
-// nrows re-read the last valid row (never written back); columns past nc are skipped.
-__device__ __forceinline__ void fgs_tile_load(float (*t)[FGS_T + 1], const float* __restrict__ g, int rw, int nrows, int col,
-                                              bool colok, int lane) {
-    if (!colok) return;
+// 64 x TC tile <-> global: a wave-load covers 64 / TC rows of TC contiguous floats (256 or 128 bytes each), 8 loads in flight.
+// Rows past nrows re-read the last valid row (never written back); columns past nc are skipped.
+// TC = 32 (round 3): two tiles take 17 KB instead of 33 KB, so a CU holds 9 of these one-wave workgroups instead of 4 - the
+// kernel lives on other waves covering a wave's load / solve / store phases.  WLS of a 16-bit map + its 8-bit view, 640x480, per frame
+// of a 128- or 1024-frame call: 29.1 us with 64-column tiles, 25.1 with 32, 32.4 with 16 (64-byte row segments).
+template <int TC>
+__device__ __forceinline__ void fgs_tile_load(float (*t)[TC + 1], const float* __restrict__ g, int rw, int nrows, int c0, int nc, int lane) {
+    constexpr int SUB = FGS_T / TC;
+    const int col = lane % TC, sub = lane / TC;
+    if (col >= nc) return;
 #pragma unroll 1
-    for (int r = 0; r < FGS_T; r += 8) {
+    for (int r = 0; r < FGS_T; r += 8 * SUB) {
         float a[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = g[(size_t)min(r + u, nrows - 1) * rw + col];
+        for (int u = 0; u < 8; u++) a[u] = g[(size_t)min(r + u * SUB + sub, nrows - 1) * rw + c0 + col];
 #pragma unroll
-        for (int u = 0; u < 8; u++) t[r + u][lane] = a[u];
+        for (int u = 0; u < 8; u++) t[r + u * SUB + sub][col] = a[u];
     }
 }
-__device__ __forceinline__ void fgs_tile_store(const float (*t)[FGS_T + 1], float* __restrict__ g, int rw, int nrows, int col,
-                                               bool colok, int lane) {
-    if (!colok) return;
-    for (int r = 0; r < nrows; r++) g[(size_t)r * rw + col] = t[r][lane];
+template <int TC>
+__device__ __forceinline__ void fgs_tile_store(const float (*t)[TC + 1], float* __restrict__ g, int rw, int nrows, int c0, int nc, int lane) {
+    constexpr int SUB = FGS_T / TC;
+    const int col = lane % TC, sub = lane / TC;
+    if (col >= nc) return;
+    for (int r = sub; r < nrows; r += SUB) g[(size_t)r * rw + c0 + col] = t[r][col];
 }
+template <int TC>
 __global__ __launch_bounds__(64) void k_fgs_hpass_tiles(float* __restrict__ cur, const float* __restrict__ wh, float* __restrict__ tmp,
                                                    int rw, int rh, int K, float lambda) {
-    __shared__ float t_c[FGS_T][FGS_T + 1], t_w[FGS_T][FGS_T + 1];   // t_w: the weights on the way in, the super-diagonal on the way out / back in
-    float (*const t_t)[FGS_T + 1] = t_w;
+    static_assert(FGS_T % TC == 0 && TC % FGS_R == 0, "tile shape");
+    __shared__ float t_c[FGS_T][TC + 1], t_w[FGS_T][TC + 1];   // t_w: the weights on the way in, the super-diagonal on the way out / back in
+    float (*const t_t)[TC + 1] = t_w;
     const int img = blockIdx.y, f = img / K, lane = threadIdx.x;
     const int r0 = blockIdx.x * FGS_T, nrows = min(FGS_T, rh - r0);
     float* curI = cur + ((size_t)img * rh + r0) * rw;
     float* tmpI = tmp + ((size_t)img * rh + r0) * rw;
     const float* whI = wh + ((size_t)f * rh + r0) * rw;
     float prev_cur = 0.0f, prev_tmp = 0.0f, coef_prev = 0.0f;
-    const int nchunks = (rw + FGS_T - 1) / FGS_T;
+    const int nchunks = (rw + TC - 1) / TC;
     for (int c = 0; c < nchunks; c++) {
-        const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
-        fgs_tile_load(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
-        fgs_tile_load(t_w, whI, rw, nrows, c0 + lane, lane < nc, lane);
+        const int c0 = c * TC, nc = min(TC, rw - c0);
+        fgs_tile_load<TC>(t_c, curI, rw, nrows, c0, nc, lane);
+        fgs_tile_load<TC>(t_w, whI, rw, nrows, c0, nc, lane);
         __syncthreads();
         // rows past nrows solve garbage that is never written back
         for (int j0 = 0; j0 < nc; j0 += FGS_R) {
@@ -1821,17 +1830,17 @@ __global__ __launch_bounds__(64) void k_fgs_hpass_tiles(float* __restrict__ cur,
             for (int u = 0; u < FGS_R; u++) { t_c[lane][j0 + u] = cc[u]; t_t[lane][j0 + u] = tt[u]; }
         }
         __syncthreads();
-        fgs_tile_store(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
-        fgs_tile_store(t_t, tmpI, rw, nrows, c0 + lane, lane < nc, lane);
+        fgs_tile_store<TC>(t_c, curI, rw, nrows, c0, nc, lane);
+        fgs_tile_store<TC>(t_t, tmpI, rw, nrows, c0, nc, lane);
         __syncthreads();
     }
     float next = 0.0f;
     for (int c = nchunks - 1; c >= 0; c--) {
-        const int c0 = c * FGS_T, nc = min(FGS_T, rw - c0);
-        fgs_tile_load(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
-        fgs_tile_load(t_t, tmpI, rw, nrows, c0 + lane, lane < nc, lane);
+        const int c0 = c * TC, nc = min(TC, rw - c0);
+        fgs_tile_load<TC>(t_c, curI, rw, nrows, c0, nc, lane);
+        fgs_tile_load<TC>(t_t, tmpI, rw, nrows, c0, nc, lane);
         __syncthreads();
-        for (int j0 = FGS_T - FGS_R; j0 >= 0; j0 -= FGS_R) {
+        for (int j0 = TC - FGS_R; j0 >= 0; j0 -= FGS_R) {
             float cc[FGS_R], tt[FGS_R];
 #pragma unroll
             for (int u = 0; u < FGS_R; u++) { cc[u] = t_c[lane][j0 + u]; tt[u] = t_t[lane][j0 + u]; }
@@ -1848,7 +1857,7 @@ __global__ __launch_bounds__(64) void k_fgs_hpass_tiles(float* __restrict__ cur,
             for (int u = 0; u < FGS_R; u++) t_c[lane][j0 + u] = cc[u];
         }
         __syncthreads();
-        fgs_tile_store(t_c, curI, rw, nrows, c0 + lane, lane < nc, lane);
+        fgs_tile_store<TC>(t_c, curI, rw, nrows, c0, nc, lane);
         __syncthreads();
     }
 }
