@@ -385,7 +385,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define SV_COST_DEPTH 2   // image rows the gray cost kernel's loads run ahead of their use (k_cost2, STAGE path)
 #endif
 #ifndef SV_COST_ABL
-#define SV_COST_ABL 0   // diagnostic builds (wrong results): 1 C to the sink, 2 no stage reads / writes, 4 one window tap, 8 no BT arithmetic, 16 no ring
+#define SV_COST_ABL 0   // diagnostic builds (wrong results): 1 C to the sink, 4 one window tap, 8 no BT arithmetic, 16 no ring
+                        // (-DSV_COST_DRAIN: every wait of the queue a full drain, right results: tells a wrong count from a wrong index)
 #endif
 constexpr int COST_SINK_SLOTS = 256;   // sink slots of NT * N dwords each (workgroup id mod 256)
 // Gray cost (CN = 1): the right-image statistics a tile row needs - NCOL + 32 N - 1 consecutive elements of each of the
@@ -635,7 +636,8 @@ __global__ __launch_bounds__(NT) SV_COST_KATTR void k_cost2(const uint2* __restr
         };
         if constexpr (STAGE) {
             // Three vector memory streams per trip - the left record of a row to come, the stage's dwords of a row to come,
-            // the finished row of C - issued from inline assembly in that order, loads DEPTH trips ahead of their use, and
+            // the finished row of C - issued from inline assembly in that cyclic order (odd waves enter the cycle at the store:
+            // SV_COST_ST_SPREAD), loads DEPTH trips ahead of their use, and
             // waited for by hand: the wait for a load lets the K * DEPTH - 1 younger operations stay in flight, so a store
             // has DEPTH trips to be acknowledged before a wait covers it.  (Left to the compiler the waits were vmcnt(1) where
             // vmcnt(2) would do - the loop's entry and its back edge carried the operations in different orders - and every
