@@ -437,6 +437,13 @@ int sv_last_sweep_waves(const sv_ctx* ctx);
 int sv_debug_sweep_order(sv_ctx* ctx, int enable, int* launches, int* violations, long long* worst_lead_ticks,
                          long long* worst_lead_prev_ticks);
 
+/* Self-test of the one floating-point instruction the integer path uses (sv_sweep.hip.h, pk_min3): the fused sweeps take their
+ * three-input minima with gfx950's packed binary16 minimum, which equals the integer minimum on u16 values below 0x7C00 as long
+ * as the kernels keep the default f16 denormal mode.  Runs this library's own build of that function over every pair of
+ * [0, 0x7C00)^2 with a hashed third operand, both halves of the packed word (about 2e9 minima, a few ms), and returns the number
+ * that differ from the integer minimum (expected: 0).  Synchronises the context's stream.  No reference counterpart. */
+int sv_debug_selftest_min3(sv_ctx* ctx, unsigned long long* mismatches);
+
 /* Algorithmic bytes per frame of the current geometry:
  * which: 0 cost, 1 aggregation, 2 wta, 3 tail, 4 frame.                       */
 int64_t sv_algorithmic_bytes(const sv_ctx* ctx, int which);

@@ -1934,6 +1934,23 @@ int sv_debug_sweep_order(sv_ctx* c, int enable, int* launches, int* violations, 
     return SV_OK;
 }
 
+int sv_debug_selftest_min3(sv_ctx* c, unsigned long long* mismatches) {
+    if (!c || !mismatches) return SV_ERR_INVALID_ARG;
+    DevGuard g(c->device);
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 8));
+    hipError_t e = hipMemsetAsync(d, 0, 8, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(svk::k_min3_selftest, dim3(0x7C00), dim3(256), 0, c->stream, d, 0x7C00u);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches, d, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return SV_OK;
+}
+
 int sv_set_debug(sv_ctx* c, int enable) {
     if (!c) return SV_ERR_INVALID_ARG;
     c->debug = enable == 1;

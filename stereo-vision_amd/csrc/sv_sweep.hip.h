@@ -116,6 +116,18 @@ __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) 
     return d;
 #endif
 }
+// Self-test of that claim with this library's own build of pk_min3 (sv_debug_selftest_min3): block a, thread-strided b over
+// [0, lim)^2, a hashed third operand, both halves of the packed word, against the integer minimum.
+__global__ __launch_bounds__(256) void k_min3_selftest(unsigned long long* bad, uint32_t lim) {
+    const uint32_t a = blockIdx.x;
+    unsigned long long n = 0;
+    for (uint32_t b = threadIdx.x; b < lim; b += blockDim.x) {
+        const uint32_t c = ((a * 2654435761u) ^ (b * 40503u) ^ (b >> 3)) % lim, c2 = (c * 7u + a) % lim;
+        const uint32_t got = pk_min3(a | (b << 16), b | (c << 16), c | (c2 << 16));
+        n += got != (min(min(a, b), c) | (min(min(b, c), c2) << 16));
+    }
+    if (n) atomicAdd(bad, n);
+}
 template <int N>
 __device__ __forceinline__ void sweep_path(const uint32_t (&c)[N], const uint32_t (&r)[N], uint32_t dd, uint32_t P1P1,
                                            uint32_t (&L)[N], uint32_t& mn_out, uint32_t big0, uint32_t big15) {

@@ -33,7 +33,7 @@ EXPORTS = (
     "sv_wls_roi", "sv_filter_wls_dev", "sv_filter_wls_host", "sv_filter_blf_dev", "sv_filter_blf_host", "sv_filter_blf_joint_dev", "sv_filter_blf_joint_host", "sv_compute_rgb_batch_dev", "sv_disparity_vis_batch_dev", "sv_depth_batch_dev", "sv_world_image_dev", "sv_world_image_host",
     "sv_synchronize", "sv_last_aggregation", "sv_init_rectify_map", "sv_update_mapper", "sv_get_maps_host", "sv_get_mapper_host",
     "sv_set_debug", "sv_debug_read_volume_host", "sv_debug_read_plane_host", "sv_enable_timing", "sv_get_timings",
-    "sv_algorithmic_bytes", "sv_last_error", "sv_version", "sv_get_aggregation_timings", "sv_filter_speckles_static_dev", "sv_last_sweep_waves", "sv_debug_sweep_order", "sv_compute_rgb_vis_host",
+    "sv_algorithmic_bytes", "sv_last_error", "sv_version", "sv_get_aggregation_timings", "sv_filter_speckles_static_dev", "sv_last_sweep_waves", "sv_debug_sweep_order", "sv_debug_selftest_min3", "sv_compute_rgb_vis_host",
     "sv_pool_create", "sv_pool_destroy", "sv_pool_size", "sv_pool_plan", "sv_pool_compute_gray_host", "sv_pool_last_error")
 STATIC_MAX_PIXELS = 1920 * 1088   # SV_STATIC_MAX_PIXELS
 
@@ -134,6 +134,7 @@ def load():
     L.sv_get_aggregation_timings.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]
     L.sv_filter_speckles_static_dev.argtypes = [vp, vp, i32, i32]
     L.sv_last_sweep_waves.argtypes = [vp]
+    L.sv_debug_selftest_min3.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.sv_debug_sweep_order.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.sv_pool_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), i32, i32, i32, C.POINTER(Params), i32]
     L.sv_pool_destroy.argtypes = [vp]
@@ -433,6 +434,12 @@ class Matcher:
 
     def synchronize(self):
         self._chk(self._L.sv_synchronize(self._h))
+
+    def selftest_min3(self):
+        """sv_debug_selftest_min3: mismatches of the sweeps' packed binary16 three-input minimum against the integer minimum."""
+        n = C.c_ulonglong(1)
+        self._chk(self._L.sv_debug_selftest_min3(self._h, C.byref(n)))
+        return int(n.value)
 
     def set_debug(self, on=True):
         self._chk(self._L.sv_set_debug(self._h, int(on)))

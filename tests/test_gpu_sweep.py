@@ -300,3 +300,11 @@ def test_sweep_value_range_gate(gpu, P2, sweeps):
     assert np.array_equal(m.debug_plane(2)[:, D:], st["mins"][:, D:]), "minS differs"
     assert np.array_equal(got, ref)
     m.close()
+
+
+def test_packed_f16_minimum_is_the_integer_minimum(gpu):
+    """The library's own build of pk_min3 against the integer minimum on every pair of [0, 0x7C00)^2 (both halves, hashed third
+    operand): the claim the sweeps' arithmetic rests on, under the flags libsv_hip was compiled with."""
+    m = svhip.Matcher(96, 40, svhip.default_params(32, 8))
+    assert m.selftest_min3() == 0
+    m.close()
