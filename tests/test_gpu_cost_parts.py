@@ -47,3 +47,15 @@ def test_parts_equal_the_one_part_kernel_on_a_wide_frame(gpu):
     finally:
         del os.environ["SV_COST_NOPARTS"]
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("D", [32, 64, 96, 128])
+@pytest.mark.parametrize("bs", [1, 3, 5, 7, 9, 11])
+def test_batches_every_block_size_up_to_128_disparities(gpu, D, bs):
+    """The large-batch form of the gray cost kernel (64-column tiles, LDS stage, hand-counted memory queue; 32-column tiles where the
+    ring of a 64-column tile would pass the LDS) at every block size: nine frames, each against the oracle.  The window radius is a
+    compile-time case of the kernel's row loop, so every radius is a different piece of code (and register allocation)."""
+    W, H, nb = D + 83, 29 + bs, 9
+    pairs, po, got = _batch(W, H, D, nb, 5100 + D + bs, block_size=bs, P1=8 * bs * bs, P2=32 * bs * bs, pre_filter_cap=31)
+    for i in range(nb):
+        assert np.array_equal(got[i], svref.sgbm(pairs[i][0], pairs[i][1], po)), "frame %d of D=%d bs=%d" % (i, D, bs)
